@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpix/s of dense pyramidal LK flow on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A step = one frame pair: load the new frame's level 0 (already resident in HBM), build its pyramid, run every
+pyramid level coarse->fine against the previous frame's pyramid, swap.  That is main.cu:246-272 of the reference.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k|vga] [--mode lk_float|compat_cpu]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame pair is row-sharded over the ranks with
+a halo exchange per pyramid level over RCCL (cuda_optical_flow_2_amd/parallel.py) -- strong scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {  # BASELINE.json configs: (width, height, levels, window)
+    "vga": (640, 480, 3, 5),
+    "1080p": (1920, 1080, 4, 7),
+    "4k": (3840, 2160, 5, 9),
+    "8k": (7680, 4320, 6, 15),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+LK_BYTES_PER_PX = 10   # fused level kernel: 2 u8 read + one (u,v) float pair written
+
+
+def cpu_baseline(workload, w, h, levels, window):
+    """The reference's own CPU path (oracle/_ref, kind 'reference') or the oracle port, 1 thread, bounded sample."""
+    import numpy as np
+
+    import oracle as orc
+    from cuda_optical_flow_2_amd import synth
+
+    # bounded sample: full pipeline on a pair whose size keeps the run at ~10-20 s on one core
+    sw, sh = (w, h) if w * h <= 3840 * 2160 else (3840, 2160)
+    p, n = synth.smooth_pair(sw, sh)
+    p3, n3 = synth.to_3ch(p), synth.to_3ch(n)
+    use_ref = orc.have_reference() and window == 9
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        if use_ref:
+            orc.Reference().flow_pair(p3, n3, levels)          # cpu::gauss_pyramid x2 + cpu::calc_optical_flow per level
+        else:
+            orc.Oracle().flow_pair(p3, n3, levels, window, "compat_cpu")
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or reps >= 8:
+            break
+    return {
+        "value": round(sw * sh * reps / dt / 1e6, 3), "unit": "Mpix/s", "cores": 1,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"{reps} pair(s) {sw}x{sh}, {levels} levels, window {window}x{window}, both pyramids + all levels, "
+                  f"{'OptFlowCPU.cpp compiled as oracle/_ref' if use_ref else 'oracle/ofx_oracle.c (compat_cpu)'}, {dt:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from cuda_optical_flow_2_amd import engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h, levels, window = WORKLOADS[args.workload]
+    # a short ring of resident frames: a smooth texture translating by (2,1) px per frame
+    nframes = 4
+    frames = [synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1] for i in range(nframes)]
+    d_frames = [torch.from_numpy(f).cuda() for f in frames]
+
+    if world == 1:
+        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank)
+        sess.push_frame_host(frames[0])
+
+        def step(i):
+            sess.set_frame_device(d_frames[(i + 1) % nframes])
+            sess.build_pyramid()
+            sess.run_flow()
+            sess.swap()
+
+        driver = None
+    else:
+        from cuda_optical_flow_2_amd import parallel
+
+        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank)
+        sess = driver.session
+        driver.push_frame(d_frames[0])
+
+        def step(i):
+            driver.step(d_frames[(i + 1) % nframes])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    sess.timing(args.steps)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    k_avg_us, k_min_us, k_n = sess.timing_read()
+    sess.timing(0)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        own_rows = h if driver is None else (driver.plan.own[0][1] - driver.plan.own[0][0])
+        lk_bytes = LK_BYTES_PER_PX * w * own_rows
+        achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload)
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpix/s dense LK flow",
+            "value": round(w * h / (ms * 1e-3) / 1e6, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 5),
+            "frames_per_s": round(1e3 / ms, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "i32/f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters=1 (the only value the "
+                            f"reference defines), mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
+                "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "lk_level_kernel (level 0, fused derivatives + window sums + solve)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),
+                "launches_timed": k_n, "traffic": traffic,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, w, h, levels, window)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+// Error channel, argument checks and small queries of libofx_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "ofx_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void ofx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *ofx_last_error(void) { return g_err; }
+
+extern "C" int ofx_abi_version(void) { return 1; }
+
+extern "C" int ofx_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        ofx_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return -OFX_E_HIP;
+    }
+    return n;
+}
+
+int ofx_check_geom(const ofx_geom *g, const char *who)
+{
+    OFX_REQUIRE(g != nullptr, "%s: geometry is null", who);
+    OFX_REQUIRE(g->w > 0 && g->h > 0, "%s: bad size %dx%d", who, g->w, g->h);
+    OFX_REQUIRE(g->pitch >= g->w && (g->pitch & 3) == 0, "%s: pitch %d must be a multiple of 4 and >= w=%d", who,
+                g->pitch, g->w);
+    OFX_REQUIRE(g->rows > 0 && g->row0 >= 0 && g->row0 + g->rows <= g->h,
+                "%s: buffer rows [%d,%d) not inside the image height %d", who, g->row0, g->row0 + g->rows, g->h);
+    OFX_REQUIRE(g->out_y0 >= 0 && g->out_y0 <= g->out_y1 && g->out_y1 <= g->h, "%s: output rows [%d,%d) not inside [0,%d)",
+                who, g->out_y0, g->out_y1, g->h);
+    return OFX_OK;
+}
+
+int ofx_check_halo(const ofx_geom *g, int halo, const char *who)
+{
+    if (g->out_y1 <= g->out_y0) return OFX_OK;
+    const int lo = g->out_y0 - halo > 0 ? g->out_y0 - halo : 0;
+    const int hi = g->out_y1 + halo < g->h ? g->out_y1 + halo : g->h;
+    OFX_REQUIRE(lo >= g->row0 && hi <= g->row0 + g->rows,
+                "%s: rows [%d,%d) are needed (halo %d) but the buffer holds [%d,%d)", who, lo, hi, halo, g->row0,
+                g->row0 + g->rows);
+    return OFX_OK;
+}

@@ -1,0 +1,44 @@
+// Internal helpers shared by the HIP translation units of libofx_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ofx.h"
+
+// thread-local last-error message behind ofx_last_error()
+void ofx_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define OFX_HIP(call)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            ofx_set_error("%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);           \
+            return OFX_E_HIP;                                                                            \
+        }                                                                                                \
+    } while (0)
+
+#define OFX_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            ofx_set_error(__VA_ARGS__); \
+            return OFX_E_INVALID;       \
+        }                               \
+    } while (0)
+
+#define OFX_TRY(expr)               \
+    do {                            \
+        int rc_ = (expr);           \
+        if (rc_ != OFX_OK) return rc_; \
+    } while (0)
+
+static inline hipStream_t ofx_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int ofx_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// validates the parts of an ofx_geom every kernel relies on
+int ofx_check_geom(const ofx_geom *g, const char *who);
+
+// rows of the level that a stencil of vertical radius `halo` around [out_y0,out_y1) touches, clipped to the image,
+// must be present in the buffer
+int ofx_check_halo(const ofx_geom *g, int halo, const char *who);

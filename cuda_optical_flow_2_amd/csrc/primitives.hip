@@ -1,0 +1,331 @@
+// API-compat primitives: generic (any mask / window) device counterparts of the reference kernels that the fused
+// flow path does not use directly.  They exist so that gpu::conv_*, gpu::srm_*, gpu::inverse_matrix*,
+// gpu::grayscale_avg and gpu::bilinear_filter (OptFlowGpu.cuh:5-35) have bit-exact device implementations.
+// They are plain one-thread-per-pixel kernels with coalesced rows; the hot path lives in lk_level.hip.
+//
+// Built with -ffp-contract=off: the reference's CPU build rounds every product and sum separately, and the
+// per-tap truncation of the integer convolutions depends on that.
+#include <math.h>
+
+#include "ofx_internal.h"
+
+namespace {
+
+constexpr int kMaxTaps = 81; // masks up to 9x9 travel as kernel arguments
+
+struct MaskArg {
+    float m[kMaxTaps];
+    int mw, mh;
+};
+
+int make_mask(const float *h_mask, int mw, int mh, MaskArg *out, const char *who)
+{
+    OFX_REQUIRE(h_mask != nullptr, "%s: mask is null", who);
+    OFX_REQUIRE(mw > 0 && mh > 0 && mw * mh <= kMaxTaps, "%s: mask %dx%d unsupported (at most %d taps)", who, mw, mh, kMaxTaps);
+    for (int i = 0; i < mw * mh; ++i) out->m[i] = h_mask[i];
+    out->mw = mw;
+    out->mh = mh;
+    return OFX_OK;
+}
+
+// OptFlowGpu.cu:47-60 / OptFlowCPU.cpp:27-28
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t *src3, uint8_t *dst3, size_t n)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint8_t *s = src3 + 3 * p;
+    const uint8_t g = (uint8_t)(((int)s[0] + (int)s[1] + (int)s[2]) / 3);
+    uint8_t *d = dst3 + 3 * p;
+    d[0] = d[1] = d[2] = g;
+}
+
+// int accumulator, float add, truncation after every tap (OptFlowCPU.cpp:62,102 == OptFlowGpu.cu:137-139,414)
+__device__ __forceinline__ int acc_trunc(int acc, int px, float m) { return (int)((float)acc + (float)px * m); }
+
+// OptFlowGpu.cu:108-147 (FLOAT_ACC=false) and :282-342 (FLOAT_ACC=true, the "tiled" variant's arithmetic)
+template <bool FLOAT_ACC>
+__global__ __launch_bounds__(256) void conv_3ch_kernel(const uint8_t *src3, uint8_t *dst3, int w, int h, const MaskArg M)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = M.mw >> 1, oy = M.mh >> 1;
+    int ia[3] = {0, 0, 0};
+    float fa[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < M.mh; ++i) {
+        const int ty = y - oy + i;
+        if (ty < 0 || ty >= h) continue;
+        for (int j = 0; j < M.mw; ++j) {
+            const int tx = x - ox + j;
+            if (tx < 0 || tx >= w) continue;
+            const uint8_t *s = src3 + 3 * ((size_t)ty * w + tx);
+            const float m = M.m[i * M.mw + j];
+            if constexpr (FLOAT_ACC) {
+                fa[0] += (float)s[0] * m;
+                fa[1] += (float)s[1] * m;
+                fa[2] += (float)s[2] * m;
+            } else {
+                ia[0] = acc_trunc(ia[0], s[0], m);
+                ia[1] = acc_trunc(ia[1], s[1], m);
+                ia[2] = acc_trunc(ia[2], s[2], m);
+            }
+        }
+    }
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    if constexpr (FLOAT_ACC) {
+        d[0] = (uint8_t)(int)fa[0];
+        d[1] = (uint8_t)(int)fa[1];
+        d[2] = (uint8_t)(int)fa[2];
+    } else {
+        d[0] = (uint8_t)ia[0];
+        d[1] = (uint8_t)ia[1];
+        d[2] = (uint8_t)ia[2];
+    }
+}
+
+// OptFlowGpu.cu:380-425 (u8 out) and :1040-1090 (f32 out)
+template <bool F32_OUT>
+__global__ __launch_bounds__(256) void conv_3ch_1ch_kernel(const uint8_t *src3, int w, int h, void *dst, const MaskArg M)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = M.mw >> 1, oy = M.mh >> 1;
+    int ia = 0;
+    float fa = 0.f;
+    for (int i = 0; i < M.mh; ++i) {
+        const int ty = y - oy + i;
+        if (ty < 0 || ty >= h) continue;
+        for (int j = 0; j < M.mw; ++j) {
+            const int tx = x - ox + j;
+            if (tx < 0 || tx >= w) continue;
+            const float m = M.m[i * M.mw + j];
+            const int px = src3[3 * ((size_t)ty * w + tx)];
+            if constexpr (F32_OUT) {
+                if (m == 0.0f) continue; // OptFlowGpu.cu:1075
+                fa += (float)px * m;
+            } else {
+                ia = acc_trunc(ia, px, m);
+            }
+        }
+    }
+    if constexpr (F32_OUT)
+        static_cast<float *>(dst)[(size_t)y * w + x] = fa;
+    else
+        static_cast<uint8_t *>(dst)[(size_t)y * w + x] = (uint8_t)ia;
+}
+
+// OptFlowGpu.cu:1463-1502 / :1549-1588: window clipped at the border, taps in row-major order
+template <typename TIn, typename TAcc>
+__global__ __launch_bounds__(256) void srm_kernel(const TIn *a, const TIn *b, int w, int h, int ww, int wh, TAcc *dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = ww >> 1, oy = wh >> 1;
+    TAcc acc = 0;
+    for (int p = 0; p < wh; ++p) {
+        const int ty = y - oy + p;
+        if (ty < 0 || ty >= h) continue;
+        for (int q = 0; q < ww; ++q) {
+            const int tx = x - ox + q;
+            if (tx < 0 || tx >= w) continue;
+            const size_t t = (size_t)ty * w + tx;
+            acc += (TAcc)a[t] * (TAcc)b[t];
+        }
+    }
+    dst[(size_t)y * w + x] = acc;
+}
+
+// 2x2 solves.  variant 0: OptFlowGpu.cu:1737-1754, 1: OptFlowCPU.cpp:369-382 (c unscaled), 2: OptFlowCPU.cpp:293-304
+template <typename T>
+__global__ __launch_bounds__(256) void solve_kernel(const T *sxx, const T *syy, const T *sxy, const T *sxt, const T *syt,
+                                                    float *flow, size_t n, int variant)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float u, v;
+    if (variant == OFX_SOLVE_F32) {
+        float a = (float)sxx[p], b = (float)sxy[p], c = b, d = (float)syy[p];
+        const float pre = 1 / (a * d - b * c);
+        a *= pre;
+        b *= pre;
+        c *= pre;
+        d *= pre;
+        u = -d * (float)sxt[p] + b * (float)syt[p];
+        v = c * (float)sxt[p] - a * (float)syt[p];
+    } else {
+        double a = (double)sxx[p], b = (double)sxy[p], c = b, d = (double)syy[p];
+        const double xt = (double)sxt[p], yt = (double)syt[p];
+        const double pre = 1 / (a * d - b * c);
+        a *= pre;
+        b *= pre;
+        if (variant == OFX_SOLVE_F64) c *= pre;
+        d *= pre;
+        u = (float)(-d * xt + b * yt);
+        v = (float)(c * xt - a * yt);
+    }
+    reinterpret_cast<float2 *>(flow)[p] = make_float2(u, v);
+}
+
+// Bilateral filter (the reference calls it bilinear_filter): OptFlowGpu.cu:1984-2048 / OptFlowCPU.cpp:401-465.
+// The range weight depends only on the integer grey difference k in [-255,255], so the host evaluates
+// 1/(2 pi sB^2) * pow(e, -k^2/(2 sB^2)) with libm for k^2 of 0..255 -- the very expression the CPU path evaluates
+// per tap -- and the kernel looks it up: identical doubles, no transcendental on the device.
+constexpr int kMaxBilateral = 13;
+struct BilateralArg {
+    double range[256];
+    double spatial[kMaxBilateral * kMaxBilateral];
+};
+
+__global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t *src3, const uint8_t *gray3, uint8_t *dst3, int w, int h,
+                                                        int ww, int wh, const BilateralArg B)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = ww >> 1, oy = wh >> 1;
+    const int f0 = gray3[3 * ((size_t)y * w + x)];
+    double wsum = 0, acc[3] = {0, 0, 0};
+    for (int m = 0; m < wh; ++m) {
+        const int ty = y - oy + m;
+        if (ty < 0 || ty >= h) continue;
+        for (int n = 0; n < ww; ++n) {
+            const int tx = x - ox + n;
+            if (tx < 0 || tx >= w) continue;
+            const size_t q = (size_t)ty * w + tx;
+            int k = (int)gray3[3 * q] - f0;
+            k = k < 0 ? -k : k;
+            const double nb = B.range[k];
+            const double ns = B.spatial[m * ww + n];
+            wsum += nb * ns;
+            acc[0] += (double)src3[3 * q] * nb * ns;
+            acc[1] += (double)src3[3 * q + 1] * nb * ns;
+            acc[2] += (double)src3[3 * q + 2] * nb * ns;
+        }
+    }
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = (uint8_t)(int)(acc[0] / wsum);
+    d[1] = (uint8_t)(int)(acc[1] / wsum);
+    d[2] = (uint8_t)(int)(acc[2] / wsum);
+}
+
+inline dim3 grid2d(int w, int h) { return dim3(ofx_div_up(w, 256), h); }
+
+} // namespace
+
+// utils::generate_gaussian_kernel, OptFlowUtils.cpp:68-114 (host side, double)
+extern "C" void ofx_generate_gaussian_kernel(double sigma_s, int ks, double *dst)
+{
+    if (ks == -1) ks = (int)(2.0 * M_PI * sigma_s);
+    if (ks % 2 == 0) ks += 1;
+    const int c = ks >> 1;
+    const double s2 = sigma_s * sigma_s;
+    for (int i = 0; i < ks; ++i)
+        for (int j = 0; j < ks; ++j) {
+            const double m = (double)(i > c ? i - c : c - i), n = (double)(j > c ? j - c : c - j);
+            dst[i * ks + j] = 1.0 / (2.0 * M_PI * s2) * pow(M_E, -0.5 * (n * n + m * m) / s2);
+        }
+    double sum = 0;
+    for (int i = 0; i < ks * ks; ++i) sum += dst[i];
+    for (int i = 0; i < ks * ks; ++i) dst[i] /= sum;
+}
+
+extern "C" int ofx_grayscale_avg_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst3 && w > 0 && h > 0, "ofx_grayscale_avg_3ch: bad arguments");
+    const size_t n = (size_t)w * (size_t)h;
+    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, n);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_conv_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, const float *h_mask, int mw, int mh,
+                            int float_acc, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst3 && w > 0 && h > 0, "ofx_conv_3ch: bad arguments");
+    MaskArg M;
+    OFX_TRY(make_mask(h_mask, mw, mh, &M, "ofx_conv_3ch"));
+    if (float_acc)
+        hipLaunchKernelGGL(conv_3ch_kernel<true>, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, w, h, M);
+    else
+        hipLaunchKernelGGL(conv_3ch_kernel<false>, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, w, h, M);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_conv_3ch_1ch_u8(const uint8_t *d_src3, int w, int h, uint8_t *d_dst, const float *h_mask, int mw, int mh,
+                                   void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst && w > 0 && h > 0, "ofx_conv_3ch_1ch_u8: bad arguments");
+    MaskArg M;
+    OFX_TRY(make_mask(h_mask, mw, mh, &M, "ofx_conv_3ch_1ch_u8"));
+    hipLaunchKernelGGL(conv_3ch_1ch_kernel<false>, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, w, h, (void *)d_dst, M);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_conv_3ch_1ch_f32(const uint8_t *d_src3, int w, int h, float *d_dst, const float *h_mask, int mw, int mh,
+                                    void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst && w > 0 && h > 0, "ofx_conv_3ch_1ch_f32: bad arguments");
+    MaskArg M;
+    OFX_TRY(make_mask(h_mask, mw, mh, &M, "ofx_conv_3ch_1ch_f32"));
+    hipLaunchKernelGGL(conv_3ch_1ch_kernel<true>, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, w, h, (void *)d_dst, M);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_srm_u8(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int ww, int wh, int32_t *d_dst, void *stream)
+{
+    OFX_REQUIRE(d_a && d_b && d_dst && w > 0 && h > 0 && ww > 0 && wh > 0, "ofx_srm_u8: bad arguments");
+    hipLaunchKernelGGL((srm_kernel<uint8_t, int32_t>), grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_a, d_b, w, h, ww, wh, d_dst);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_srm_f32(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, void *stream)
+{
+    OFX_REQUIRE(d_a && d_b && d_dst && w > 0 && h > 0 && ww > 0 && wh > 0, "ofx_srm_f32: bad arguments");
+    hipLaunchKernelGGL((srm_kernel<float, float>), grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_a, d_b, w, h, ww, wh, d_dst);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_solve_i32(const int32_t *d_sxx, const int32_t *d_syy, const int32_t *d_sxy, const int32_t *d_sxt,
+                             const int32_t *d_syt, float *d_flow, int w, int h, int variant, void *stream)
+{
+    OFX_REQUIRE(d_sxx && d_syy && d_sxy && d_sxt && d_syt && d_flow && w > 0 && h > 0, "ofx_solve_i32: bad arguments");
+    OFX_REQUIRE(variant >= 0 && variant <= 2, "ofx_solve_i32: bad variant %d", variant);
+    const size_t n = (size_t)w * (size_t)h;
+    hipLaunchKernelGGL(solve_kernel<int32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_sxx, d_syy,
+                       d_sxy, d_sxt, d_syt, d_flow, n, variant);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_solve_f32(const float *d_sxx, const float *d_syy, const float *d_sxy, const float *d_sxt, const float *d_syt,
+                             float *d_flow, int w, int h, void *stream)
+{
+    OFX_REQUIRE(d_sxx && d_syy && d_sxy && d_sxt && d_syt && d_flow && w > 0 && h > 0, "ofx_solve_f32: bad arguments");
+    const size_t n = (size_t)w * (size_t)h;
+    hipLaunchKernelGGL(solve_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_sxx, d_syy,
+                       d_sxy, d_sxt, d_syt, d_flow, n, (int)OFX_SOLVE_F64);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int ww, int wh,
+                                 double sigma_s, double sigma_b, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_gray3 && d_dst3 && w > 0 && h > 0, "ofx_bilateral_3ch: bad arguments");
+    OFX_REQUIRE(ww > 0 && wh > 0 && (ww & 1) && ww <= kMaxBilateral && wh <= ww,
+                "ofx_bilateral_3ch: window %dx%d unsupported (odd ww <= %d, wh <= ww; the spatial mask is ww x ww, "
+                "OptFlowCPU.cpp:404)", ww, wh, kMaxBilateral);
+    static thread_local BilateralArg B;
+    ofx_generate_gaussian_kernel(sigma_s, ww, B.spatial);
+    const double sb2 = sigma_b * sigma_b;
+    for (int k = 0; k < 256; ++k) {
+        const double kk = (double)k * (double)k;
+        B.range[k] = 1.0 / (2.0 * M_PI * sb2) * pow(M_E, -0.5 * (kk) / sb2);
+    }
+    hipLaunchKernelGGL(bilateral_kernel, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, d_gray3, d_dst3, w, h, ww, wh, B);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}

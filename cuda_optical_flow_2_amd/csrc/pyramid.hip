@@ -1,0 +1,305 @@
+// Pyramid downsample, global shift, flow composition and layout helpers for gfx950.
+// All of these are pure streaming kernels (HBM-bound); they use 4-pixels-per-lane dword accesses where the layout
+// allows it and one wave-row mapping so that every load/store instruction touches one contiguous span.
+#include "ofx_internal.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2x decimating 3x3 Gaussian on a 1ch plane (OptFlowGpu.cu:1198-1232 / OptFlowCPU.cpp:112-148 with
+// GAUS_KERNEL_3x3 = [1 2 1]^T [1 2 1] / 16, kernels.cpp:61-64).  The reference accumulates in float and truncates;
+// with power-of-two weights and u8 inputs every partial sum is exact, so integer (sum >> 4) is bit-identical.
+// Source taps at column/row -1 are outside the image and skipped; taps 2x+1 <= 2w-1 are always inside.
+// A lane produces 4 destination pixels from source columns 8c-1 .. 8c+7.
+struct DownArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int src_pitch, src_row0, src_row_end; // source buffer holds source rows [src_row0, src_row_end)
+    int dw, dh, dst_pitch, dst_row0;      // destination level geometry
+    int out_y0, out_y1;
+};
+
+__global__ __launch_bounds__(256) void downsample_1ch_kernel(const DownArgs A)
+{
+    const int c4 = blockIdx.x * blockDim.x + threadIdx.x; // group of 4 destination columns
+    const int y = A.out_y0 + blockIdx.y;
+    const int x0 = 4 * c4;
+    if (x0 >= A.dw || y >= A.out_y1) return;
+    const int sw = 2 * A.dw;
+    int col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // vertical [1 2 1] of source columns 8c-1 .. 8c+7
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int sy = 2 * y - 1 + p;
+        if (sy < 0 || sy < A.src_row0 || sy >= A.src_row_end) continue; // sy < 2*dh always
+        const int wgt = (p == 1) ? 2 : 1;
+        const uint8_t *row = A.src + (size_t)(sy - A.src_row0) * (size_t)A.src_pitch;
+        const int sx = 2 * x0; // multiple of 8
+        uint32_t lo = 0, hi = 0;
+        // the source pitch is a multiple of 4 and >= sw, and sx < sw, so both dwords stay inside the row pitch
+        lo = *reinterpret_cast<const uint32_t *>(row + sx);
+        if (sx + 4 < A.src_pitch) hi = *reinterpret_cast<const uint32_t *>(row + sx + 4);
+        const int left = (sx > 0) ? row[sx - 1] : 0;
+        col[0] += wgt * left;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (lo >> (8 * k)) & 0xff, b = (hi >> (8 * k)) & 0xff;
+            col[1 + k] += wgt * ((sx + k < sw) ? a : 0);
+            col[5 + k] += wgt * ((sx + 4 + k < sw) ? b : 0);
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = (col[2 * k] + 2 * col[2 * k + 1] + col[2 * k + 2]) >> 4;
+        out |= (uint32_t)((x0 + k < A.dw) ? v : 0) << (8 * k); // pitch padding is written as zero
+    }
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.dst_row0) * (size_t)A.dst_pitch + x0) = out;
+}
+
+// 3-channel variant, one thread per destination pixel (API-compat path only: gpu::gauss_pyramid on colour images)
+__global__ __launch_bounds__(256) void downsample_3ch_kernel(const uint8_t *src, uint8_t *dst, int dw, int dh)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const int sw = 2 * dw;
+    int acc[3] = {0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int sy = 2 * y - 1 + p;
+        if (sy < 0) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int sx = 2 * x - 1 + q;
+            if (sx < 0) continue;
+            const int wgt = ((p == 1) ? 2 : 1) * ((q == 1) ? 2 : 1);
+            const uint8_t *s = src + 3 * ((size_t)sy * sw + sx);
+            acc[0] += wgt * s[0];
+            acc[1] += wgt * s[1];
+            acc[2] += wgt * s[2];
+        }
+    }
+    uint8_t *d = dst + 3 * ((size_t)y * dw + x);
+    d[0] = (uint8_t)(acc[0] >> 4);
+    d[1] = (uint8_t)(acc[1] >> 4);
+    d[2] = (uint8_t)(acc[2] >> 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Global shift vector: OptFlowCPU.cpp:255-266.  `i * (1 >> offset)` is 0 for offset >= 1, so every pixel reads
+// flow element 0 of each coarser level; float accumulation, coarsest level first.
+struct FlowPtrs {
+    const float *lv[OFX_MAX_LEVELS];
+};
+
+__global__ void shift_vector_kernel(const FlowPtrs P, int level, int max_level, float *uv)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float u = 0.0f, v = 0.0f;
+    for (int k = max_level - 1; k > level; --k) {
+        const float mult = (float)(1 << (k - level));
+        u += mult * P.lv[k][0];
+        v += mult * P.lv[k][1];
+    }
+    uv[0] = u;
+    uv[1] = v;
+}
+
+// cpu::shift_back_pyramid on channel 0 (OptFlowCPU.cpp:247, :268-279), destination zero-initialised:
+//   target = ((int)(x+u), (int)(y+v)) with float add and truncation toward zero; inside the image -> copy;
+//   outside (or non-finite) -> the byte the leading memcpy of w*h bytes left there: the pixel's own value when
+//   3*(y*w+x) < w*h, else 0.
+struct ShiftArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    const float *uv;
+    int w, h, pitch, row0, row_end, out_y0, out_y1;
+};
+
+__global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftArgs A)
+{
+    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = A.out_y0 + blockIdx.y;
+    if (x0 >= A.pitch || y >= A.out_y1) return;
+    const float u = A.uv[0], v = A.uv[1];
+    const float ty = (float)y + v;
+    const bool yin = ty > -1.0f && ty < (float)A.h;
+    const int ny = yin ? (int)ty : 0;
+    const bool yhave = ny >= A.row0 && ny < A.row_end;
+    const uint8_t *srow = A.src + (size_t)((yhave ? ny : A.row0) - A.row0) * (size_t)A.pitch;
+    const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
+    const long long third = (long long)A.w * (long long)A.h;
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        int val = 0;
+        if (x < A.w) {
+            const float tx = (float)x + u;
+            if (yin && yhave && tx > -1.0f && tx < (float)A.w) {
+                val = srow[(int)tx];
+            } else {
+                val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
+            }
+        }
+        out |= (uint32_t)val << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// main.cu:138-147 dense: u = sum_{k=levels-1..level} 2^(k-level) * flow_k(i>>s, j>>s); float u updated through a
+// double product (u += (double)multiplier * f)
+struct ComposeArgs {
+    FlowPtrs P;
+    float *dst;
+    int w, h, levels, level;
+};
+
+__global__ __launch_bounds__(256) void compose_flow_kernel(const ComposeArgs A)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= A.w || i >= A.h) return;
+    float u = 0.0f, v = 0.0f;
+    for (int k = A.levels - 1; k >= A.level; --k) {
+        const int sc = k - A.level;
+        const size_t pos = (size_t)(i >> sc) * (size_t)(A.w >> sc) + (size_t)(j >> sc);
+        const double m = (double)(1 << sc);
+        const float2 f = reinterpret_cast<const float2 *>(A.P.lv[k])[pos];
+        u = (float)((double)u + m * (double)f.x);
+        v = (float)((double)v + m * (double)f.y);
+    }
+    reinterpret_cast<float2 *>(A.dst)[(size_t)i * A.w + j] = make_float2(u, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void extract_ch0_kernel(const uint8_t *src3, uint8_t *dst1, int w, int h, int pitch)
+{
+    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int y = blockIdx.y;
+    if (x0 >= pitch || y >= h) return;
+    const uint8_t *s = src3 + 3 * ((size_t)y * w + x0);
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (x0 + k < w) out |= (uint32_t)s[3 * k] << (8 * k);
+    *reinterpret_cast<uint32_t *>(dst1 + (size_t)y * pitch + x0) = out;
+}
+
+__global__ __launch_bounds__(256) void replicate_3ch_kernel(const uint8_t *src1, int pitch, uint8_t *dst3, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const uint8_t v = src1[(size_t)y * pitch + x];
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = d[1] = d[2] = v;
+}
+
+} // namespace
+
+extern "C" int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_row0, int src_rows, uint8_t *d_dst,
+                                  const ofx_geom *dst, void *stream)
+{
+    OFX_TRY(ofx_check_geom(dst, "ofx_downsample_1ch"));
+    OFX_REQUIRE(d_src && d_dst, "ofx_downsample_1ch: null pointer");
+    OFX_REQUIRE(src_pitch >= 2 * dst->w && (src_pitch & 3) == 0, "ofx_downsample_1ch: src pitch %d too small for width %d",
+                src_pitch, 2 * dst->w);
+    OFX_REQUIRE(((uintptr_t)d_src & 3) == 0 && ((uintptr_t)d_dst & 3) == 0, "ofx_downsample_1ch: planes must be 4-byte aligned");
+    OFX_REQUIRE(dst->out_y0 >= dst->row0 && dst->out_y1 <= dst->row0 + dst->rows,
+                "ofx_downsample_1ch: output rows [%d,%d) not inside the destination buffer [%d,%d)", dst->out_y0, dst->out_y1,
+                dst->row0, dst->row0 + dst->rows);
+    if (dst->out_y1 <= dst->out_y0) return OFX_OK;
+    // source rows 2*y-1 .. 2*y+1 (row -1 is the border)
+    const int need_lo = 2 * dst->out_y0 - 1 > 0 ? 2 * dst->out_y0 - 1 : 0;
+    const int need_hi = 2 * (dst->out_y1 - 1) + 2;
+    OFX_REQUIRE(need_lo >= src_row0 && need_hi <= src_row0 + src_rows,
+                "ofx_downsample_1ch: source rows [%d,%d) needed, buffer holds [%d,%d)", need_lo, need_hi, src_row0,
+                src_row0 + src_rows);
+    DownArgs a{d_src,    d_dst,       src_pitch,  src_row0,   src_row0 + src_rows, dst->w,
+               dst->h,   dst->pitch,  dst->row0,  dst->out_y0, dst->out_y1};
+    const int groups = ofx_div_up(dst->w, 4);
+    dim3 grid(ofx_div_up(groups, 256), dst->out_y1 - dst->out_y0);
+    hipLaunchKernelGGL(downsample_1ch_kernel, grid, dim3(256), 0, ofx_stream(stream), a);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_downsample_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int dw, int dh, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst3 && dw > 0 && dh > 0, "ofx_downsample_3ch: bad arguments");
+    dim3 grid(ofx_div_up(dw, 256), dh);
+    hipLaunchKernelGGL(downsample_3ch_kernel, grid, dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, dw, dh);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_shift_vector(const float *const *d_flow_levels, int level, int max_level, float *d_uv, void *stream)
+{
+    OFX_REQUIRE(d_flow_levels && d_uv, "ofx_shift_vector: null pointer");
+    OFX_REQUIRE(max_level >= 1 && max_level <= OFX_MAX_LEVELS && level >= 0 && level < max_level,
+                "ofx_shift_vector: bad level %d of %d", level, max_level);
+    FlowPtrs p{};
+    for (int k = level + 1; k < max_level; ++k) {
+        OFX_REQUIRE(d_flow_levels[k] != nullptr, "ofx_shift_vector: flow level %d is null", k);
+        p.lv[k] = d_flow_levels[k];
+    }
+    hipLaunchKernelGGL(shift_vector_kernel, dim3(1), dim3(64), 0, ofx_stream(stream), p, level, max_level, d_uv);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream)
+{
+    OFX_TRY(ofx_check_geom(g, "ofx_shift_1ch"));
+    OFX_REQUIRE(d_src && d_dst && d_uv, "ofx_shift_1ch: null pointer");
+    OFX_REQUIRE(d_src != d_dst, "ofx_shift_1ch: in-place shift is not supported");
+    OFX_REQUIRE(g->out_y0 >= g->row0 && g->out_y1 <= g->row0 + g->rows, "ofx_shift_1ch: output rows outside the buffer");
+    if (g->out_y1 <= g->out_y0) return OFX_OK;
+    ShiftArgs a{d_src, d_dst, d_uv, g->w, g->h, g->pitch, g->row0, g->row0 + g->rows, g->out_y0, g->out_y1};
+    dim3 grid(ofx_div_up(g->pitch / 4, 256), g->out_y1 - g->out_y0);
+    hipLaunchKernelGGL(shift_1ch_kernel, grid, dim3(256), 0, ofx_stream(stream), a);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_compose_flow(const float *const *d_flow_levels, int w, int h, int levels, int level, float *d_dst,
+                                void *stream)
+{
+    OFX_REQUIRE(d_flow_levels && d_dst && w > 0 && h > 0, "ofx_compose_flow: bad arguments");
+    OFX_REQUIRE(levels >= 1 && levels <= OFX_MAX_LEVELS && level >= 0 && level < levels, "ofx_compose_flow: bad level");
+    ComposeArgs a{};
+    for (int k = level; k < levels; ++k) {
+        OFX_REQUIRE(d_flow_levels[k] != nullptr, "ofx_compose_flow: flow level %d is null", k);
+        a.P.lv[k] = d_flow_levels[k];
+    }
+    a.dst = d_dst;
+    a.w = w;
+    a.h = h;
+    a.levels = levels;
+    a.level = level;
+    dim3 grid(ofx_div_up(w, 256), h);
+    hipLaunchKernelGGL(compose_flow_kernel, grid, dim3(256), 0, ofx_stream(stream), a);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_extract_ch0(const uint8_t *d_src3, uint8_t *d_dst1, int w, int h, int dst_pitch, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst1 && w > 0 && h > 0, "ofx_extract_ch0: bad arguments");
+    OFX_REQUIRE(dst_pitch >= w && (dst_pitch & 3) == 0 && ((uintptr_t)d_dst1 & 3) == 0, "ofx_extract_ch0: bad pitch/alignment");
+    dim3 grid(ofx_div_up(dst_pitch / 4, 256), h);
+    hipLaunchKernelGGL(extract_ch0_kernel, grid, dim3(256), 0, ofx_stream(stream), d_src3, d_dst1, w, h, dst_pitch);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_replicate_3ch(const uint8_t *d_src1, int src_pitch, uint8_t *d_dst3, int w, int h, void *stream)
+{
+    OFX_REQUIRE(d_src1 && d_dst3 && w > 0 && h > 0 && src_pitch >= w, "ofx_replicate_3ch: bad arguments");
+    dim3 grid(ofx_div_up(w, 256), h);
+    hipLaunchKernelGGL(replicate_3ch_kernel, grid, dim3(256), 0, ofx_stream(stream), d_src1, src_pitch, d_dst3, w, h);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}

@@ -1,0 +1,268 @@
+"""Host-side mirror of the engine's C ABI (include/ofx.h) for Python callers.
+
+PyTorch is used only as plumbing: device memory (``torch.empty(..., device='cuda')``), streams and, in
+``parallel.py``, ``torch.distributed``.  All arithmetic runs in libofx_hip.so; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import lib as _lib
+from .lib import Geom, MODES, OfxError, Params, check
+
+_vp = C.c_void_p
+
+
+def _stream_ptr(stream=None) -> Optional[int]:
+    """hipStream_t of a torch stream (None -> torch's current stream)."""
+    import torch
+
+    st = stream if stream is not None else torch.cuda.current_stream()
+    return st.cuda_stream or None
+
+
+def pitch_for(w: int) -> int:
+    return (w + 63) // 64 * 64
+
+
+class DeviceView:
+    """Zero-copy torch view of a device range owned by the C session (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, shape, typestr: str, strides=None):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": tuple(shape), "typestr": typestr,
+                                         "strides": strides, "version": 2}
+
+    def tensor(self):
+        import torch
+
+        return torch.as_tensor(self, device="cuda")
+
+
+class Session:
+    """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
+
+    def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
+                 shard=None):
+        self.L = _lib.load()
+        self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
+        p = Params()
+        p.width, p.height, p.levels, p.window, p.mode, p.device = width, height, levels, window, MODES[mode], device
+        self.shard = shard
+        if shard is not None:
+            p.sharded = 1
+            for k in range(levels):
+                p.own_y0[k], p.own_y1[k] = shard.own[k]
+                p.buf_y0[k], p.buf_y1[k] = shard.buf[k]
+        self._h = _vp()
+        check(self.L.ofx_session_create(C.byref(p), C.byref(self._h)), "ofx_session_create")
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            check(self.L.ofx_session_destroy(self._h), "ofx_session_destroy")
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- frames
+    def set_frame_host(self, gray1: np.ndarray, stream=None):
+        gray1 = np.ascontiguousarray(gray1, dtype=np.uint8)
+        assert gray1.shape == (self.height, self.width), gray1.shape
+        self._keep = [gray1]
+        check(self.L.ofx_session_set_frame_host(self._h, gray1.ctypes.data, _stream_ptr(stream)), "set_frame_host")
+
+    def set_frame_host_3ch(self, img3: np.ndarray, stream=None):
+        img3 = np.ascontiguousarray(img3, dtype=np.uint8)
+        assert img3.shape == (self.height, self.width, 3), img3.shape
+        self._keep = [img3]
+        check(self.L.ofx_session_set_frame_host_3ch(self._h, img3.ctypes.data, _stream_ptr(stream)), "set_frame_host_3ch")
+
+    def set_frame_device(self, t, stream=None):
+        """t: torch uint8 CUDA tensor (height, width), row stride = t.stride(0)."""
+        assert t.is_cuda and t.dtype.itemsize == 1 and tuple(t.shape) == (self.height, self.width)
+        check(self.L.ofx_session_set_frame_device(self._h, t.data_ptr(), int(t.stride(0)), _stream_ptr(stream)),
+              "set_frame_device")
+
+    # ---- steps
+    def build_pyramid(self, stream=None):
+        check(self.L.ofx_session_build_pyramid(self._h, _stream_ptr(stream)), "build_pyramid")
+
+    def downsample_level(self, level: int, stream=None):
+        check(self.L.ofx_session_downsample_level(self._h, level, _stream_ptr(stream)), "downsample_level")
+
+    def run_flow(self, stream=None):
+        check(self.L.ofx_session_run_flow(self._h, _stream_ptr(stream)), "run_flow")
+
+    def compute_uv(self, level: int, stream=None):
+        check(self.L.ofx_session_compute_uv(self._h, level, _stream_ptr(stream)), "compute_uv")
+
+    def run_level(self, level: int, stream=None):
+        check(self.L.ofx_session_run_level(self._h, level, _stream_ptr(stream)), "run_level")
+
+    def swap(self):
+        check(self.L.ofx_session_swap(self._h), "swap")
+
+    def push_frame_host(self, gray1: np.ndarray, stream=None):
+        """Load a frame, build its pyramid and make it the previous frame (priming step of main.cu:203-209)."""
+        self.set_frame_host(gray1, stream)
+        self.build_pyramid(stream)
+        self.swap()
+
+    # ---- timing of the level-0 fused kernel (HIP events on the launch stream)
+    def timing(self, max_launches: int):
+        check(self.L.ofx_session_timing(self._h, max_launches), "session_timing")
+
+    def timing_read(self):
+        avg, mn, n = C.c_double(), C.c_double(), C.c_int()
+        check(self.L.ofx_session_timing_read(self._h, C.byref(avg), C.byref(mn), C.byref(n)), "session_timing_read")
+        return avg.value, mn.value, n.value
+
+    # ---- buffers
+    def plane(self, which: int, level: int):
+        """(torch uint8 view [rows, pitch], Geom) of plane 0=prev 1=next 2=shifted."""
+        ptr, g = _vp(), Geom()
+        check(self.L.ofx_session_plane(self._h, which, level, C.byref(ptr), C.byref(g)), "session_plane")
+        return DeviceView(ptr.value, (g.rows, g.pitch), "|u1").tensor(), g
+
+    def flow(self, level: int):
+        """torch float32 view [own_rows, w, 2] of the level's flow, and the global index of its first row."""
+        ptr, r0, rows = _vp(), C.c_int(), C.c_int()
+        check(self.L.ofx_session_flow(self._h, level, C.byref(ptr), C.byref(r0), C.byref(rows)), "session_flow")
+        w = self.width >> level
+        return DeviceView(ptr.value, (rows.value, w, 2), "<f4").tensor(), r0.value
+
+    def uv(self, level: int):
+        ptr = _vp()
+        check(self.L.ofx_session_shift_uv(self._h, level, C.byref(ptr)), "session_shift_uv")
+        return DeviceView(ptr.value, (2,), "<f4").tensor()
+
+    def flow_host(self, level: int, stream=None) -> np.ndarray:
+        ptr, r0, rows = _vp(), C.c_int(), C.c_int()
+        check(self.L.ofx_session_flow(self._h, level, C.byref(ptr), C.byref(r0), C.byref(rows)), "session_flow")
+        out = np.empty((rows.value, self.width >> level, 2), np.float32)
+        check(self.L.ofx_session_get_flow_host(self._h, level, out.ctypes.data, _stream_ptr(stream)), "get_flow_host")
+        return out
+
+
+# ---- stateless device-pointer calls on torch tensors -------------------------------------------------------------
+
+def _u8_plane(arr: np.ndarray):
+    """Upload an (h, w) u8 array into a pitched CUDA tensor; returns (tensor[h, pitch], pitch)."""
+    import torch
+
+    h, w = arr.shape
+    pitch = pitch_for(w)
+    t = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
+    t[:, :w] = torch.from_numpy(np.ascontiguousarray(arr)).cuda()
+    return t, pitch
+
+
+def lk_level(prev1: np.ndarray, next1: np.ndarray, window: int, mode: str, want_sums: bool = False,
+             rows: Optional[Sequence[int]] = None, buf_rows: Optional[Sequence[int]] = None):
+    """One fused LK level on host arrays (upload, ofx_lk_level[_sums], download).
+
+    rows=(y0,y1) restricts the produced rows; buf_rows=(r0,r1) uploads only those rows (shard emulation)."""
+    import torch
+
+    L = _lib.load()
+    h, w = prev1.shape
+    r0, r1 = buf_rows if buf_rows is not None else (0, h)
+    y0, y1 = rows if rows is not None else (0, h)
+    tp, pitch = _u8_plane(prev1[r0:r1])
+    tn, _ = _u8_plane(next1[r0:r1])
+    g = Geom(w, h, pitch, r0, r1 - r0, y0, y1)
+    st = _stream_ptr()
+    if want_sums:
+        out = torch.zeros((5, y1 - y0, w), dtype=torch.int32, device="cuda")
+        check(L.ofx_lk_level_sums(tp.data_ptr(), tn.data_ptr(), C.byref(g), window, MODES[mode], out.data_ptr(), y0, st),
+              "ofx_lk_level_sums")
+    else:
+        out = torch.zeros((y1 - y0, w, 2), dtype=torch.float32, device="cuda")
+        check(L.ofx_lk_level(tp.data_ptr(), tn.data_ptr(), C.byref(g), window, MODES[mode], out.data_ptr(), y0, st),
+              "ofx_lk_level")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def downsample_1ch(src1: np.ndarray) -> np.ndarray:
+    import torch
+
+    L = _lib.load()
+    sh, sw = src1.shape
+    h, w = sh >> 1, sw >> 1
+    ts, sp = _u8_plane(src1)
+    dp = pitch_for(w)
+    td = torch.zeros((h, dp), dtype=torch.uint8, device="cuda")
+    g = Geom.full(w, h, dp)
+    check(L.ofx_downsample_1ch(ts.data_ptr(), sp, 0, sh, td.data_ptr(), C.byref(g), _stream_ptr()), "ofx_downsample_1ch")
+    torch.cuda.synchronize()
+    return td[:, :w].cpu().numpy()
+
+
+def shift_1ch(src1: np.ndarray, uv) -> np.ndarray:
+    import torch
+
+    L = _lib.load()
+    h, w = src1.shape
+    ts, pitch = _u8_plane(src1)
+    td = torch.zeros_like(ts)
+    tuv = torch.tensor(list(uv), dtype=torch.float32, device="cuda")
+    g = Geom.full(w, h, pitch)
+    check(L.ofx_shift_1ch(ts.data_ptr(), td.data_ptr(), C.byref(g), tuv.data_ptr(), _stream_ptr()), "ofx_shift_1ch")
+    torch.cuda.synchronize()
+    return td[:, :w].cpu().numpy()
+
+
+def shift_vector(flow_levels: List[Optional[np.ndarray]], level: int, max_level: int) -> np.ndarray:
+    import torch
+
+    L = _lib.load()
+    keep, ptrs = [], (_vp * _lib.OFX_MAX_LEVELS)()
+    for k in range(level + 1, max_level):
+        t = torch.from_numpy(np.ascontiguousarray(flow_levels[k], dtype=np.float32)).cuda()
+        keep.append(t)
+        ptrs[k] = t.data_ptr()
+    out = torch.zeros(2, dtype=torch.float32, device="cuda")
+    check(L.ofx_shift_vector(ptrs, level, max_level, out.data_ptr(), _stream_ptr()), "ofx_shift_vector")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def compose_flow(flow_levels: List[np.ndarray], levels: int, level: int) -> np.ndarray:
+    import torch
+
+    L = _lib.load()
+    keep, ptrs = [], (_vp * _lib.OFX_MAX_LEVELS)()
+    for k in range(level, levels):
+        t = torch.from_numpy(np.ascontiguousarray(flow_levels[k], dtype=np.float32)).cuda()
+        keep.append(t)
+        ptrs[k] = t.data_ptr()
+    h, w, _ = flow_levels[level].shape
+    out = torch.zeros((h, w, 2), dtype=torch.float32, device="cuda")
+    check(L.ofx_compose_flow(ptrs, w, h, levels, level, out.data_ptr(), _stream_ptr()), "ofx_compose_flow")
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def flow_pair(prev1: np.ndarray, next1: np.ndarray, levels: int, window: int, mode: str) -> List[np.ndarray]:
+    """Whole pair through a Session: returns the flow pyramid as host arrays."""
+    import torch
+
+    h, w = prev1.shape
+    s = Session(w, h, levels, window, mode)
+    try:
+        s.push_frame_host(prev1)
+        s.set_frame_host(next1)
+        s.build_pyramid()
+        s.run_flow()
+        torch.cuda.synchronize()
+        return [s.flow_host(k) for k in range(levels)]
+    finally:
+        s.close()

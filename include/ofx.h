@@ -1,0 +1,220 @@
+/*
+ * ofx.h -- C ABI of the MI355X dense pyramidal Lucas-Kanade engine (libofx_hip.so).
+ *
+ * This is the drop-in boundary for the reference's hot path: plain pointers and
+ * sizes, no C++ or torch types.  The reference exposes the same path as C++
+ * free functions (OptFlowGpu.cuh:5-35); include/OptFlowGpu.cuh in this repo
+ * re-declares that surface and implements it on top of the entry points below
+ * (INTEGRATION.md shows the binding).  Every entry point names the reference
+ * interface it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success, an OFX_E_* code otherwise, and never
+ *     throws; ofx_last_error() returns the message of the calling thread's last
+ *     failure (the reference returns void and checks nothing).
+ *   - "d_" pointers are DEVICE pointers, "h_" pointers are HOST pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Device
+ *     entry points only enqueue work; they never synchronise or allocate.
+ *   - "3ch" images are HWC interleaved u8, 3 bytes per pixel, tightly packed
+ *     (the reference's layout, main.cu:95-104).  "1ch" planes are u8 with a row
+ *     pitch in bytes that is a multiple of 4 and >= w.
+ *   - flow is interleaved (u,v) float32, 2*w floats per row, tightly packed
+ *     (OptFlowGpu.cu:1844-1845).
+ *   - window sizes are the reference's ww/wh (full size, not radius).
+ */
+#ifndef OFX_H
+#define OFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OFX_OK 0
+#define OFX_E_INVALID 1     /* bad argument (size, alignment, unsupported window ...) */
+#define OFX_E_HIP 2         /* a HIP runtime call failed; message holds hipGetErrorString */
+#define OFX_E_UNSUPPORTED 3 /* valid request this build does not implement */
+#define OFX_E_STATE 4       /* session used out of order */
+
+/* which reference semantics a flow level follows */
+#define OFX_MODE_COMPAT_CPU 0 /* cpu::calc_optical_flow, OptFlowCPU.cpp:312-399: wrapped-u8 derivatives,
+                                 Gaussian It, inline solve (c unscaled) */
+#define OFX_MODE_LK_FLOAT 1   /* gpu::calc_opt_flow, OptFlowGpu.cu:1909-1979: float derivatives, Dt_3x3,
+                                 double solve */
+
+#define OFX_MAX_LEVELS 12
+
+const char *ofx_last_error(void);
+/* library/ABI version, bumped when a signature changes */
+int ofx_abi_version(void);
+/* number of visible HIP devices, or a negative OFX_E code */
+int ofx_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * Geometry of one pyramid level as seen by one rank.  Unsharded use:
+ * row0 = 0, rows = h, out_y0 = 0, out_y1 = h.  Row-sharded use:
+ * the plane buffers hold global rows [row0, row0+rows) -- the rank's block plus
+ * halo -- and the kernels produce global rows [out_y0, out_y1).  Rows outside
+ * [0,h) are the image border (taps skipped, as the reference does); rows inside
+ * [0,h) that a stencil needs must be present in the buffer or the call fails
+ * with OFX_E_INVALID.
+ * ---------------------------------------------------------------------- */
+typedef struct ofx_geom {
+    int w, h;   /* global width / height of this level */
+    int pitch;  /* bytes per row of the 1ch planes (multiple of 4, >= w) */
+    int row0;   /* global row index held in buffer row 0 */
+    int rows;   /* rows present in the buffers */
+    int out_y0; /* first global row to produce */
+    int out_y1; /* one past the last global row to produce */
+} ofx_geom;
+
+/* ---- hot path, device-resident ------------------------------------------ */
+
+/* One level of dense LK, fully fused: 3x3 derivative stencils, the five
+ * windowed sums of products and the 2x2 solve in one kernel.
+ * Replaces the device work of gpu::calc_opt_flow (OptFlowGpu.cu:1930-1964) /
+ * cpu::calc_optical_flow steps 1-3 (OptFlowCPU.cpp:329-384) for one level.
+ * d_next must already be shifted (ofx_shift_1ch) when level != top.
+ * d_flow receives rows [out_y0,out_y1) at row offset (y - flow_row0).
+ * window: odd, 3..23 (lk_float) / 3..25 (compat_cpu). */
+int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
+                 float *d_flow, int flow_row0, void *stream);
+
+/* Same level, but stopping before the solve: writes the five window sums
+ * (Sxx, Syy, Sxy, Sxt, Syt) as int32 planes of w ints per row.  Test/inspection
+ * entry point; equals five gpu::srm_1ch(_float) calls (OptFlowGpu.cu:1944-1960). */
+int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
+                      int32_t *d_sums5, int flow_row0, void *stream);
+
+/* 2x decimating 3x3 Gaussian on a 1ch plane: dst(x,y) = trunc(sum G[p][q] *
+ * src(2x-1+q, 2y-1+p)), taps outside the source skipped.  Replaces one level
+ * of gpu::gauss_pyramid (OptFlowGpu.cu:1198-1232) / cpu::downscale_gaussian
+ * (OptFlowCPU.cpp:112-148) for grey images.  `dst` describes the destination
+ * level; the source level is (2*dst->w) x (2*dst->h) and src_row0/src_rows say
+ * which of its rows d_src holds. */
+int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_row0, int src_rows,
+                       uint8_t *d_dst, const ofx_geom *dst, void *stream);
+
+/* Translation the reference applies to `next` below the top level:
+ * (u,v) = sum_{k=top..level+1} 2^(k-level) * flow_k[pixel 0]  in float, coarsest
+ * first (OptFlowCPU.cpp:255-266, where `i * (1 >> offset)` is always 0).
+ * d_flow_levels[k] = device pointer to level k's flow (only k > level are read).
+ * Writes 2 floats to d_uv. */
+int ofx_shift_vector(const float *const *d_flow_levels, int level, int max_level, float *d_uv, void *stream);
+
+/* dst(x,y) = src((int)(x+u), (int)(y+v)) when that lands inside the image,
+ * else src(x,y) if 3*(y*w+x) < w*h else 0 -- cpu::shift_back_pyramid
+ * (OptFlowCPU.cpp:241-282) on channel 0 with the destination zero-initialised.
+ * (u,v) is read from d_uv on the device.  Source rows needed but absent from
+ * the buffer make the affected pixels undefined; the caller sizes halos. */
+int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream);
+
+/* main.cu:138-147: dense flow at `level` = sum_k 2^(k-level) flow_k(y>>s, x>>s). */
+int ofx_compose_flow(const float *const *d_flow_levels, int w, int h, int levels, int level, float *d_dst,
+                     void *stream);
+
+/* ---- layout helpers ------------------------------------------------------ */
+int ofx_extract_ch0(const uint8_t *d_src3, uint8_t *d_dst1, int w, int h, int dst_pitch, void *stream);
+int ofx_replicate_3ch(const uint8_t *d_src1, int src_pitch, uint8_t *d_dst3, int w, int h, void *stream);
+
+/* ---- API-compat primitives, device-resident -------------------------------
+ * Generic (any mask / window size) counterparts of the reference kernels that
+ * the flow path does not use in fused form. */
+/* gpu::grayscale_avg, OptFlowGpu.cu:47-60 */
+int ofx_grayscale_avg_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, void *stream);
+/* gpu::conv_3ch_2d / _constant, OptFlowGpu.cu:108-147 (int accumulators, per-tap truncation) */
+int ofx_conv_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, const float *h_mask, int mw, int mh,
+                 int float_acc, void *stream);
+/* gpu::conv_3ch_1ch_constant / _tiled, OptFlowGpu.cu:380-425 */
+int ofx_conv_3ch_1ch_u8(const uint8_t *d_src3, int w, int h, uint8_t *d_dst, const float *h_mask, int mw, int mh,
+                        void *stream);
+/* gpu::conv_3ch_1ch_tiled_uchar_float, OptFlowGpu.cu:1040-1090 */
+int ofx_conv_3ch_1ch_f32(const uint8_t *d_src3, int w, int h, float *d_dst, const float *h_mask, int mw, int mh,
+                         void *stream);
+/* gpu::gauss_pyramid one level on 3ch images, OptFlowGpu.cu:1198-1232 (mask fixed to GAUS_KERNEL_3x3) */
+int ofx_downsample_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int dw, int dh, void *stream);
+/* gpu::srm_1ch, OptFlowGpu.cu:1463-1502 */
+int ofx_srm_u8(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int ww, int wh, int32_t *d_dst, void *stream);
+/* gpu::srm_1ch_float, OptFlowGpu.cu:1549-1588 (row-major float accumulation) */
+int ofx_srm_f32(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, void *stream);
+/* gpu::inverse_matrix, OptFlowGpu.cu:1727-1755 */
+int ofx_solve_i32(const int32_t *d_sxx, const int32_t *d_syy, const int32_t *d_sxy, const int32_t *d_sxt,
+                  const int32_t *d_syt, float *d_flow, int w, int h, int variant, void *stream);
+/* gpu::inverse_matrix_float, OptFlowGpu.cu:1819-1846 */
+int ofx_solve_f32(const float *d_sxx, const float *d_syy, const float *d_sxy, const float *d_sxt,
+                  const float *d_syt, float *d_flow, int w, int h, void *stream);
+/* solve variants for ofx_solve_i32 */
+#define OFX_SOLVE_F64 0        /* OptFlowGpu.cu:1737-1754, double, correct */
+#define OFX_SOLVE_INLINE_CPU 1 /* OptFlowCPU.cpp:369-382, double, c unscaled */
+#define OFX_SOLVE_F32 2        /* OptFlowCPU.cpp:293-304, float */
+/* utils::generate_gaussian_kernel, OptFlowUtils.cpp:68-114 (host arithmetic, double; dst holds ks*ks values,
+ * (ks+1)^2 when ks is even, 2*pi*sigma rounded when ks == -1) */
+void ofx_generate_gaussian_kernel(double sigma_s, int kernel_size, double *h_dst);
+/* gpu::bilinear_filter (a bilateral filter), OptFlowGpu.cu:1984-2048 */
+int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int ww, int wh,
+                      double sigma_s, double sigma_b, void *stream);
+
+/* ---- session: device-resident pyramids for a stream of frames -------------
+ * Mirrors main.cu:192-272: the previous frame's pyramid is kept, each new
+ * frame gets its pyramid built and every level is solved coarse to fine. */
+typedef struct ofx_session ofx_session;
+
+typedef struct ofx_params {
+    int width, height; /* level-0 size; (width>>k, height>>k) must be even for k < levels-1 */
+    int levels;        /* 1..OFX_MAX_LEVELS (main.cu:192 uses 4) */
+    int window;        /* reference: 9 (CPU, OptFlowCPU.cpp:344) / 19 (GPU, OptFlowGpu.cu:1944) */
+    int mode;          /* OFX_MODE_* */
+    int device;        /* HIP device ordinal */
+    /* Row sharding.  sharded == 0: this session holds whole levels.  sharded != 0: for level k this
+     * rank OWNS global rows [own_y0[k], own_y1[k]) -- it computes the pyramid and the flow for them -- and its
+     * plane buffers HOLD rows [buf_y0[k], buf_y1[k]) (own rows plus halo; the halo rows are filled by the
+     * caller's exchange between ofx_session_downsample_level and ofx_session_run_level). */
+    int sharded;
+    int own_y0[OFX_MAX_LEVELS], own_y1[OFX_MAX_LEVELS];
+    int buf_y0[OFX_MAX_LEVELS], buf_y1[OFX_MAX_LEVELS];
+    int reserved[8];
+} ofx_params;
+
+int ofx_session_create(const ofx_params *p, ofx_session **out);
+int ofx_session_destroy(ofx_session *s);
+/* Load the NEXT frame's level 0 (1ch, tightly packed w bytes per row, full frame) from host / device memory. */
+int ofx_session_set_frame_host(ofx_session *s, const uint8_t *h_gray1, void *stream);
+int ofx_session_set_frame_host_3ch(ofx_session *s, const uint8_t *h_img3, void *stream);
+int ofx_session_set_frame_device(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream);
+/* Build the next frame's pyramid (gpu::gauss_pyramid, main.cu:250): ofx_session_downsample_level for k = 1..levels-1. */
+int ofx_session_build_pyramid(ofx_session *s, void *stream);
+/* Level k of the next frame's pyramid from level k-1, own rows only. */
+int ofx_session_downsample_level(ofx_session *s, int level, void *stream);
+/* All levels coarse->fine against the previous frame's pyramid (main.cu:256-262): for each level
+ * ofx_session_compute_uv, then ofx_session_run_level. */
+int ofx_session_run_flow(ofx_session *s, void *stream);
+/* Shift vector of `level` from the coarser flows' pixel 0 into the session's uv slot (meaningful on the rank that
+ * owns row 0; a sharded driver broadcasts the slot before ofx_session_run_level). */
+int ofx_session_compute_uv(ofx_session *s, int level, void *stream);
+/* Shift (below the top level) + fused LK of one level, own rows, using the uv slot as it stands. */
+int ofx_session_run_level(ofx_session *s, int level, void *stream);
+/* prev <- next (main.cu:270-272). */
+int ofx_session_swap(ofx_session *s);
+/* Device pointers / geometry of the session's buffers. which: 0 = prev, 1 = next, 2 = shifted scratch. */
+int ofx_session_plane(ofx_session *s, int which, int level, uint8_t **d_ptr, ofx_geom *geom);
+int ofx_session_flow(ofx_session *s, int level, float **d_ptr, int *row0, int *rows);
+int ofx_session_shift_uv(ofx_session *s, int level, float **d_uv);
+/* Copy one level's flow (the rows this session owns, tightly packed) to host, synchronising `stream`. */
+int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst, void *stream);
+
+/* Time the level-0 fused LK launch with HIP events recorded on the launch stream: arm for up to max_launches
+ * launches (0 disarms); read returns the average/minimum duration in microseconds and re-arms. */
+int ofx_session_timing(ofx_session *s, int max_launches);
+int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int *launches);
+
+/* ---- host-pointer convenience used by the gpu:: compat surface ------------ */
+/* gpu::calc_opt_flow (OptFlowGpu.cuh:33): host 3ch images in, host flow pyramid in/out. */
+int ofx_calc_opt_flow_host(const uint8_t *h_prev3, const uint8_t *h_next3, int w, int h, float **h_flow_pyr,
+                           int level, int max_level, int window, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OFX_H */

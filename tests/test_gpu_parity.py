@@ -1,0 +1,330 @@
+"""GPU: parity of the HIP path (through the C ABI / the gpu:: drop-in surface) against the CPU oracle, the committed
+golden fixtures, and -- at BASELINE.json's full sizes -- size-independent properties.
+
+Tolerances: integer stages bit-exact; solve <= 1 float32 ulp with identical NaN/Inf mask (the HIP
+path replays the reference's operation order in IEEE double, so it is in practice bit-identical and the tests
+assert exact equality where the oracle uses the same exact window sums).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_flow_close, assert_same
+from cuda_optical_flow_2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cuda_optical_flow_2_amd import engine
+
+    return engine
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from cuda_optical_flow_2_amd.compat import GpuCompat
+
+    return GpuCompat()
+
+
+def _oracle_level(oracle, p, n, win, mode):
+    p3, n3 = synth.to_3ch(p), synth.to_3ch(n)
+    h, w = p.shape
+    fl = [np.zeros((h, w, 2), np.float32)]
+    if mode == "compat_cpu":
+        oracle.calc_optical_flow_cpu(p3, n3, fl, 0, 1, win)
+    else:
+        oracle.calc_opt_flow_gpu(p3, n3, fl, 0, 1, win, exact_sums=True)
+    return fl[0]
+
+
+def _oracle_sums(oracle, p, n, win, mode):
+    _, _, _, sums = oracle.level_planes(synth.to_3ch(p), synth.to_3ch(n), win, 0 if mode == "compat_cpu" else 1, exact_sums=True)
+    return sums
+
+
+# ---- the fused level kernel ------------------------------------------------------------------------------------------
+
+SHAPES = [(64, 48), (300, 37), (517, 64), (3, 5), (1, 1), (5, 1), (241, 9), (1000, 20)]
+
+
+@pytest.mark.parametrize("mode", ["compat_cpu", "lk_float"])
+@pytest.mark.parametrize("win", [3, 5, 7, 9, 15, 19, 23])
+def test_level_sums_and_flow(eng, oracle, mode, win):
+    for (w, h) in SHAPES:
+        for gen in ("smooth", "random"):
+            p, n = synth.smooth_pair(w, h, 0.6, -0.4) if gen == "smooth" else synth.random_pair(w, h, seed=w + h)
+            want = _oracle_sums(oracle, p, n, win, mode)
+            got = eng.lk_level(p, n, win, mode, want_sums=True)
+            if mode == "compat_cpu":
+                assert_same(got, want.astype(np.int64).astype(np.int32), f"sums {w}x{h} {gen} w{win}")
+            else:  # the oracle's planes are float (rounded once); the kernel's are the exact integers
+                assert_same(got.astype(np.float32), want.astype(np.float32), f"sums {w}x{h} {gen} w{win}")
+            assert_same(eng.lk_level(p, n, win, mode), _oracle_level(oracle, p, n, win, mode), f"flow {w}x{h} {gen} w{win} {mode}")
+
+
+def test_level_window_25_compat_only(eng, oracle):
+    p, n = synth.random_pair(130, 40, seed=9)
+    assert_same(eng.lk_level(p, n, 25, "compat_cpu"), _oracle_level(oracle, p, n, 25, "compat_cpu"), "w25 compat")
+    from cuda_optical_flow_2_amd.lib import OfxError
+
+    with pytest.raises(OfxError):
+        eng.lk_level(p, n, 25, "lk_float")  # int32 window sums could overflow: refused, not wrapped
+    with pytest.raises(OfxError):
+        eng.lk_level(p, n, 8, "lk_float")   # even windows are not defined for the fused path
+
+
+def test_level_flat_image_gives_nan(eng, oracle):
+    """det == 0 everywhere: the reference divides by zero (no threshold) and so must we -- identical NaN mask."""
+    p = np.full((40, 70), 77, np.uint8)
+    for mode in ("compat_cpu", "lk_float"):
+        got = eng.lk_level(p, p, 9, mode)
+        want = _oracle_level(oracle, p, p, 9, mode)
+        assert_same(got, want, "flat " + mode)
+        assert np.isnan(got[10:30, 10:60]).all()
+
+
+def test_level_against_float_order_oracle(eng, oracle):
+    """vs the reference's row-major float accumulation (OptFlowGpu.cu:1569-1586): sums within 361*2^-24 of sum|ab|."""
+    p, n = synth.smooth_pair(200, 120, 0.6, -0.4)
+    _, _, _, ordered = oracle.level_planes(synth.to_3ch(p), synth.to_3ch(n), 19, 1, exact_sums=False)
+    ix, iy, it, _ = oracle.level_planes(synth.to_3ch(p), synth.to_3ch(n), 19, 1, want_sums=False)
+    got = eng.lk_level(p, n, 19, "lk_float", want_sums=True).astype(np.float64)
+    pairs = ((ix, ix), (iy, iy), (ix, iy), (ix, it), (iy, it))
+    for k, (a, b) in enumerate(pairs):
+        bound = oracle.srm_1ch_f32(np.abs(a), np.abs(b), 19, 19, exact=True).astype(np.float64) * (361 * 2.0 ** -24)
+        assert (np.abs(got[k] - ordered[k]) <= bound + 1e-6).all(), f"plane {k}"
+
+
+@pytest.mark.parametrize("mode", ["compat_cpu", "lk_float"])
+def test_level_row_sharding_is_bit_exact(eng, mode):
+    """a level computed in row blocks (buffers = block + halo) equals the unsharded level bit for bit."""
+    p, n = synth.random_pair(333, 90, seed=4)
+    win, halo = 9, 9 // 2 + 1
+    whole = eng.lk_level(p, n, win, mode)
+    cuts = [0, 17, 18, 51, 90]
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        b0, b1 = max(0, y0 - halo), min(90, y1 + halo)
+        part = eng.lk_level(p, n, win, mode, rows=(y0, y1), buf_rows=(b0, b1))
+        assert_same(part, whole[y0:y1], f"rows [{y0},{y1})")
+    from cuda_optical_flow_2_amd.lib import OfxError
+
+    with pytest.raises(OfxError):  # halo too small: refused, never read out of the buffer
+        eng.lk_level(p, n, win, mode, rows=(20, 40), buf_rows=(18, 42))
+
+
+# ---- pyramid / shift / compose -----------------------------------------------------------------------------------------
+
+def test_downsample(eng, oracle):
+    for (w, h) in ((128, 96), (10, 6), (2, 2), (518, 34), (3840, 16)):
+        img = synth.random_pair(w, h, seed=h)[0]
+        assert_same(eng.downsample_1ch(img), oracle.downscale_gaussian(synth.to_3ch(img))[:, :, 0], f"downsample {w}x{h}")
+
+
+def test_shift_golden_and_oracle(eng, oracle, golden):
+    g = golden("shift")
+    img = g["img"][:, :, 0]
+    for i in range(len(g["uv"])):
+        levels = [None, g[f"f1_{i}"], g[f"f2_{i}"]]
+        uv = eng.shift_vector(levels, 0, 3)
+        assert_same(eng.shift_1ch(img, uv), g[f"shift_{i}"][:, :, 0], f"shift case {i}")
+    big = synth.random_pair(1001, 77, seed=8)[0]
+    for uv in ((3.7, -2.2), (-1000.5, 0.0), (0.0, 76.5), (-0.999, -0.999)):
+        fl = [None, np.array([[[uv[0] / 2, uv[1] / 2]]], np.float32)]
+        got_uv = eng.shift_vector(fl, 0, 2)
+        assert_same(eng.shift_1ch(big, got_uv), oracle.shift_back_pyramid(synth.to_3ch(big), 0, 2, fl)[:, :, 0], f"shift {uv}")
+
+
+def test_compose_flow(eng, oracle):
+    rng = np.random.default_rng(5)
+    fl = [rng.normal(size=(48 >> k, 64 >> k, 2)).astype(np.float32) for k in range(3)]
+    for level in (0, 1, 2):
+        assert_same(eng.compose_flow(fl, 3, level), oracle.compose_flow(fl, 3, level), f"compose to level {level}")
+
+
+# ---- whole pairs through the session -----------------------------------------------------------------------------------
+
+def test_pair_golden_compat_cpu(eng, golden):
+    """3-level 64x48 pipeline golden produced by the reference's own cpu::calc_optical_flow (window 9)."""
+    g = golden("levels")
+    got = eng.flow_pair(g["pair_prev"], g["pair_next"], 3, 9, "compat_cpu")
+    for k in range(3):
+        assert_flow_close(got[k], g[f"pair_flow_L{k}"], 1, f"pipeline flow L{k}")
+        assert_same(got[k], g[f"pair_flow_L{k}"], f"pipeline flow L{k} (bit-exact)")
+    for tag in ("smooth", "random"):
+        one = eng.flow_pair(g[tag + "_prev"], g[tag + "_next"], 1, 9, "compat_cpu")[0]
+        assert_same(one, g[tag + "_flow_single"], "single level " + tag)
+
+
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 5), (320, 240, 4, 19), (256, 192, 3, 9)])
+@pytest.mark.parametrize("mode", ["compat_cpu", "lk_float"])
+def test_pair_vs_oracle(eng, oracle, cfg, mode):
+    w, h, levels, win = cfg  # first entry is BASELINE config[0]: 640x480, 3 levels, 5x5
+    p, n = synth.smooth_pair(w, h)
+    got = eng.flow_pair(p, n, levels, win, mode)
+    want, pp, npyr = oracle.flow_pair(synth.to_3ch(p), synth.to_3ch(n), levels, win, mode, exact_sums=True)
+    for k in range(levels):
+        assert_same(got[k], want[k], f"{mode} L{k}")
+
+
+def test_session_planes_and_streaming(eng, oracle):
+    """Pyramid planes equal the oracle's, and prev/next swap keeps the previous pyramid (main.cu:270-272)."""
+    import torch
+
+    w, h, L = 192, 128, 3
+    frames = [synth.smooth_pair(w, h, dx, 0.5 * dx, seed=77)[1] for dx in (0.0, 1.0, 2.5)]
+    s = eng.Session(w, h, L, 7, "lk_float")
+    s.push_frame_host(frames[0])
+    for i in (1, 2):
+        s.set_frame_host(frames[i])
+        s.build_pyramid()
+        s.run_flow()
+        torch.cuda.synchronize()
+        want, pp, npyr = oracle.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), L, 7, "lk_float", exact_sums=True)
+        for k in range(L):
+            plane, g = s.plane(1, k)
+            assert_same(plane[:, : g.w].cpu().numpy(), npyr[k][:, :, 0], f"next pyramid L{k}")
+            assert_same(s.flow_host(k), want[k], f"frame {i} flow L{k}")
+        s.swap()
+    s.close()
+
+
+def test_session_rejects_bad_configs(eng):
+    from cuda_optical_flow_2_amd.lib import OfxError
+
+    with pytest.raises(OfxError):
+        eng.Session(100, 50, 3, 9)       # 50>>1 = 25 is odd but gets downsampled again
+    with pytest.raises(OfxError):
+        eng.Session(64, 48, 3, 8)        # even window
+    s = eng.Session(64, 48, 2, 5)
+    with pytest.raises(OfxError):
+        s.run_flow()                     # no frames yet
+    s.close()
+
+
+# ---- the gpu:: drop-in surface (mangled C++ symbols, host pointers) -------------------------------------------------------
+
+def test_gpu_namespace_primitives_golden(gpu, golden):
+    g = golden("primitives")
+    img, gray = g["img"], g["gray"]
+    assert_same(gpu.grayscale_avg(img), gray, "gpu::grayscale_avg")
+    for nm, m in (("dx", gpu.Dx_3x3), ("dy", gpu.Dy_3x3), ("dt", gpu.Dt_3x3), ("gaus", gpu.GAUS_KERNEL_3x3)):
+        for variant in ("conv_3ch_1ch_constant", "conv_3ch_1ch_tiled"):
+            assert_same(gpu.conv_3ch_1ch(gray, m, variant=variant), g["conv1_" + nm], f"gpu::{variant} {nm}")
+        for variant in ("conv_3ch_2d", "conv_3ch_2d_constant"):
+            assert_same(gpu.conv_3ch(img, m, 3, 3, variant), g["conv3_" + nm], f"gpu::{variant} {nm}")
+    assert_same(gpu.conv_3ch_1ch(gray, g["mask5"], 5, 5), g["conv1_m5"], "gpu::conv_3ch_1ch_constant 5x5")
+    assert_same(gpu.conv_3ch(img, g["mask5"], 5, 5), g["conv3_m5"], "gpu::conv_3ch_2d 5x5")
+    assert_same(gpu.gauss_pyramid(img, 2)[1], g["down"], "gpu::gauss_pyramid")
+    for ww, wh in ((3, 3), (5, 5), (7, 7), (9, 9), (15, 15), (19, 19), (5, 9), (4, 6)):
+        for variant in ("srm_1ch", "srm_1ch_tiled"):
+            assert_same(gpu.srm_1ch(g["a"], g["b"], ww, wh, variant), g[f"srm_{ww}x{wh}"], f"gpu::{variant} {ww}x{wh}")
+
+
+def test_gpu_namespace_float_primitives(gpu, oracle):
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for m in (gpu.Dx_3x3, gpu.Dy_3x3, gpu.Dt_3x3, gpu.Dt_3x3_n, gpu.GAUS_KERNEL_5x5):
+        k = 5 if m.size == 25 else 3
+        assert_same(gpu.conv_3ch_1ch_float(img, m, k, k), oracle.conv_3ch_to_1ch_f32(img, m, k, k), "conv f32")
+    a = rng.normal(size=(33, 41)).astype(np.float32) * 100
+    b = rng.normal(size=(33, 41)).astype(np.float32) * 100
+    for ww, wh in ((19, 19), (9, 9), (3, 7), (4, 6)):
+        assert_same(gpu.srm_1ch_float(a, b, ww, wh), oracle.srm_1ch_f32(a, b, ww, wh), f"gpu::srm_1ch_float {ww}x{wh}")
+    s = [rng.integers(-5000, 5000, (20, 30)).astype(np.int32) for _ in range(5)]
+    s[0], s[1] = np.abs(s[0]), np.abs(s[1])
+    for k in range(3):
+        s[k][0, 0] = 0
+    assert_flow_close(gpu.inverse_matrix(*s), oracle.inverse_matrix_i32(*s), 1, "gpu::inverse_matrix")
+    sf = [x.astype(np.float32) * 1.5 for x in s]
+    assert_flow_close(gpu.inverse_matrix_float(*sf), oracle.inverse_matrix_f32(*sf), 1, "gpu::inverse_matrix_float")
+    assert_same(gpu.conv_3ch(img, gpu.Dt_3x3_n, 3, 3, "conv_3ch_tiled"),
+                np.stack([oracle.conv_3ch_to_1ch_f32(np.repeat(img[:, :, c:c + 1], 3, 2), gpu.Dt_3x3_n).astype(np.int32).astype(np.uint8)
+                          for c in range(3)], axis=2), "gpu::conv_3ch_tiled (float accumulators)")
+
+
+def test_gpu_calc_opt_flow_matches_reference_composition(gpu, oracle):
+    """gpu::calc_opt_flow (window 19, Dt_3x3) over a 3-level pyramid, host pointers, vs the oracle's restatement of
+    OptFlowGpu.cu:1909-1979."""
+    p, n = synth.smooth_pair(160, 120)
+    got, gp, gn = gpu.flow_pair(synth.to_3ch(p), synth.to_3ch(n), 3)
+    want, pp, npyr = oracle.flow_pair(synth.to_3ch(p), synth.to_3ch(n), 3, 19, "lk_float", exact_sums=True)
+    for k in range(3):
+        assert_same(gn[k], npyr[k], f"pyramid L{k}")
+        assert_same(got[k], want[k], f"flow L{k}")
+    # and against the float-order variant within the solve tolerance on well-conditioned pixels
+    loose, _, _ = oracle.flow_pair(synth.to_3ch(p), synth.to_3ch(n), 3, 19, "lk_float", exact_sums=False)
+    ok = np.isfinite(loose[0]) & np.isfinite(got[0])
+    assert np.abs(got[0][ok] - loose[0][ok]).max() < 1e-2 * (1 + np.abs(loose[0][ok]).max())
+
+
+def test_gpu_bilinear_filter_golden(gpu, golden):
+    g = golden("bilateral")
+    assert_same(gpu.bilinear_filter(g["gray"], g["gray"], 9, 9, 2.0, 10.0), g["out_gray_9"], "gpu::bilinear_filter 9x9 (main.cu:240)")
+    assert_same(gpu.bilinear_filter(g["img"], g["gray"], 5, 5, 1.5, 20.0), g["out_color_5"], "gpu::bilinear_filter 5x5")
+
+
+# ---- BASELINE full sizes: size-independent properties -----------------------------------------------------------------
+
+FULL = [(1920, 1080, 4, 7), (3840, 2160, 5, 9)]
+
+
+@pytest.mark.parametrize("cfg", FULL)
+def test_full_size_crops_match_oracle(eng, oracle, cfg):
+    """A level-0 interior block depends only on its (radius+1)-pixel neighbourhood, so oracle crops pin the 4K/1080p
+    result without running the oracle on the whole frame."""
+    w, h, levels, win = cfg
+    p, n = synth.smooth_pair(w, h)
+    r = win // 2 + 1
+    whole = eng.lk_level(p, n, win, "lk_float")
+    rng = np.random.default_rng(w)
+    boxes = [(0, 0), (w - 160, h - 96), (w - 160, 0), (0, h - 96)] + [(int(rng.integers(0, w - 160)), int(rng.integers(0, h - 96))) for _ in range(4)]
+    for (x0, y0) in boxes:
+        x1, y1 = x0 + 160, y0 + 96
+        cx0, cy0, cx1, cy1 = max(0, x0 - r), max(0, y0 - r), min(w, x1 + r), min(h, y1 + r)
+        # keep true image borders as borders, cut everywhere else with a full halo
+        want = _oracle_level(oracle, p[cy0:cy1, cx0:cx1], n[cy0:cy1, cx0:cx1], win, "lk_float")
+        assert_same(whole[y0:y1, x0:x1], want[y0 - cy0:y1 - cy0, x0 - cx0:x1 - cx0], f"crop at ({x0},{y0})")
+
+
+@pytest.mark.parametrize("cfg", FULL)
+def test_full_size_properties(eng, cfg):
+    import torch
+
+    w, h, levels, win = cfg
+    p, n = synth.smooth_pair(w, h)
+    # (1) identical frames: every temporal sum is 0, so the flow is exactly (+-0, +-0) wherever the system is regular
+    same = eng.lk_level(p, p, win, "lk_float")
+    fin = np.isfinite(same)
+    assert fin.mean() > 0.99 and (same[fin] == 0).all()
+    # (2) two row blocks with halo == whole frame, bit for bit
+    whole = eng.lk_level(p, n, win, "lk_float")
+    cut, halo = h // 2 + 3, win // 2 + 1
+    top = eng.lk_level(p, n, win, "lk_float", rows=(0, cut), buf_rows=(0, cut + halo))
+    bot = eng.lk_level(p, n, win, "lk_float", rows=(cut, h), buf_rows=(cut - halo, h))
+    assert_same(np.concatenate([top, bot]), whole, "two-block sharding")
+    # (3) the session pipeline reproduces the stand-alone level at the top of the pyramid and is deterministic
+    s = eng.Session(w, h, levels, win, "lk_float")
+    s.push_frame_host(p)
+    s.set_frame_host(n)
+    s.build_pyramid()
+    s.run_flow()
+    torch.cuda.synchronize()
+    a = [s.flow_host(k) for k in range(levels)]
+    s.run_flow()
+    torch.cuda.synchronize()
+    b = [s.flow_host(k) for k in range(levels)]
+    for k in range(levels):
+        assert_same(a[k], b[k], f"determinism L{k}")
+    top_prev, g = s.plane(0, levels - 1)
+    top_next, _ = s.plane(1, levels - 1)
+    lone = eng.lk_level(top_prev[:, : g.w].cpu().numpy(), top_next[:, : g.w].cpu().numpy(), win, "lk_float")
+    assert_same(a[levels - 1], lone, "top level")
+    # (4) median level-0 residual on the smooth texture is finite
+    med = np.nanmedian(a[0].reshape(-1, 2), axis=0)
+    assert np.isfinite(med).all()
+    s.close()
