@@ -21,7 +21,9 @@ ARCH = "gfx950"
 
 SOURCES = ["lk_level.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp", "compat_gpu.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
+# -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
+# buys nothing on gfx950 (packed fp32 issues at half the rate of scalar fp32; tools/ubench/valu_rates.hip)
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]
 
 

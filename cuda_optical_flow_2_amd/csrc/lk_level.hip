@@ -20,6 +20,10 @@
 // Border semantics follow the reference exactly: image taps outside the image contribute nothing
 // (OptFlowCPU.cpp:98, OptFlowGpu.cu:1066-1075) and window taps outside the image are skipped
 // (OptFlowCPU.cpp:182-191) -- i.e. the image and the derivative planes are zero-extended.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "ofx_internal.h"
 
 namespace {
@@ -36,15 +40,31 @@ struct LkArgs {
 };
 
 // value of x held by lane (lane + D); 0 where that lane does not exist.  gfx9 DPP whole-wave shifts.
+// One whole-wave shift by a single lane.  The empty asm makes the moved value opaque so that hipcc's DPP combiner
+// cannot fold the move into its consumer: with ROCm 7.2 the folded form (v_subrev_u32_dpp) gave results shifted by
+// one lane in the compat_cpu derivative stage (found by the parity test; tools/dbg.py shows the impulse response).
+__device__ __forceinline__ int lane_shift_right(int x) // lane l receives lane l-1's value
+{
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ int lane_shift_left(int x) // lane l receives lane l+1's value
+{
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 template <int D>
 __device__ __forceinline__ int lane_from(int x)
 {
     if constexpr (D == 0) {
         return x;
     } else if constexpr (D > 0) {
-        return lane_from<D - 1>(__builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true));
+        return lane_from<D - 1>(lane_shift_left(x));
     } else {
-        return lane_from<D + 1>(__builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true));
+        return lane_from<D + 1>(lane_shift_right(x));
     }
 }
 
@@ -116,6 +136,23 @@ __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
 // MODE 0: inline loop of cpu::calc_optical_flow, OptFlowCPU.cpp:369-382 -- int sums, `c` left unscaled.
 // Same operation order as the reference, in double, with IEEE division; this file is built with
 // -ffp-contract=off so no product/sum pair is fused.
+// 1/x in double, x an integer-valued double of moderate magnitude (|x| < 2^57, no subnormals involved).
+// v_rcp_f64 seed, one Newton step to ~1 ulp, then Markstein's correction r = fma(-x,p,1); p = fma(p,r,p), which
+// yields the correctly rounded quotient (the only exception, an all-ones significand, needs |x| >= 2^52).  x == 0
+// gives +-Inf like the IEEE division the reference performs.  8 instructions instead of the ~13 of the generic
+// division expansion (div_scale/div_fmas/div_fixup handle ranges that cannot occur here).
+__device__ __forceinline__ double recip_f64(double x)
+{
+    double p = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    return x == 0.0 ? __builtin_copysign(__builtin_inf(), x) : p;
+}
+
 template <int MODE>
 __device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int syt, float &u, float &v)
 {
@@ -133,21 +170,13 @@ __device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int
         xt = (double)sxt;
         yt = (double)syt;
     }
-    const double pre = 1.0 / (a * d - b * c);
+    const double pre = recip_f64(a * d - b * c);
     a *= pre;
     b *= pre;
     if constexpr (MODE == OFX_MODE_LK_FLOAT) c *= pre;
     d *= pre;
     u = (float)(-d * xt + b * yt);
     v = (float)(c * xt - a * yt);
-}
-
-__device__ __forceinline__ void unpack4(uint32_t d, int (&o)[4])
-{
-    o[0] = d & 0xff;
-    o[1] = (d >> 8) & 0xff;
-    o[2] = (d >> 16) & 0xff;
-    o[3] = d >> 24;
 }
 
 // geometry of a wave tile for radius R (also used by the host)
@@ -158,15 +187,155 @@ struct TileGeom {
     static constexpr int OUT_W = (HI_LANE - LO_LANE + 1) * 4;
 };
 
+// ---- rows ---------------------------------------------------------------------------------------------------------
+// MI355X VALU cost model (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt): v_add_u32 / v_and / fp32 add,
+// mul, fma issue in ~2 cycles per wave; integer multiply, bfe, DPP, SDWA, packed-16 and every fp64 op take ~4.
+// So the arithmetic below is done in fp32 on values that are small exact integers (|Ix|,|Iy| <= 1020,
+// |It| <= 3825, products < 2^22), and only the running sums are 32-bit integers.
+template <int MODE>
+struct Row; // one image row of this lane's 4 columns, unpacked
+template <>
+struct Row<OFX_MODE_LK_FLOAT> {
+    float p[4]; // prev
+    float d[4]; // next - prev   (It is linear: Dt (*) next - Dt (*) prev == Dt (*) (next - prev), OptFlowGpu.cu:1936-1940)
+};
+template <>
+struct Row<OFX_MODE_COMPAT_CPU> {
+    int p[4]; // prev
+    int n[4]; // next
+};
+
+__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_LK_FLOAT> &r)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.p[j] = (float)((praw >> (8 * j)) & 0xffu); // v_cvt_f32_ubyteN
+        r.d[j] = (float)((nraw >> (8 * j)) & 0xffu) - r.p[j];
+    }
+}
+
+__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_COMPAT_CPU> &r)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.p[j] = (praw >> (8 * j)) & 0xff;
+        r.n[j] = (nraw >> (8 * j)) & 0xff;
+    }
+}
+
+__device__ __forceinline__ float lane_from_f(float x, bool left)
+{
+    const int xi = __float_as_int(x);
+    return __int_as_float(left ? lane_from<-1>(xi) : lane_from<1>(xi));
+}
+
+__device__ __forceinline__ float fmask(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
+
+// Derivatives of the middle row of a 3-row window at this lane's 4 columns, as exact small integers held in floats.
+// cm[j] = all-ones when column j is inside the image.  Only Ix and Iy are masked: every product the window sums use
+// has Ix or Iy as a factor, so a zero (Ix,Iy) pair removes the pixel whatever It is.
+__device__ __forceinline__ void derivs(const Row<OFX_MODE_LK_FLOAT> &t, const Row<OFX_MODE_LK_FLOAT> &m,
+                                       const Row<OFX_MODE_LK_FLOAT> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
+                                       float (&it)[4])
+{
+    // separable Sobel pair (kernels.cpp:6-19): sm = [1 2 1]^T column sums, df = [-1 0 1]^T column differences;
+    // Dt_3x3 = [1 2 1]^T [1 2 1] - centre tap (kernels.cpp:20-24) applied to d = next - prev
+    float sm[6], df[6], g[6];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sm[j + 1] = __builtin_fmaf(2.0f, m.p[j], t.p[j]) + b.p[j];
+        df[j + 1] = b.p[j] - t.p[j];
+        g[j + 1] = __builtin_fmaf(2.0f, m.d[j], t.d[j]) + b.d[j];
+    }
+    sm[0] = lane_from_f(sm[4], true);
+    sm[5] = lane_from_f(sm[1], false);
+    df[0] = lane_from_f(df[4], true);
+    df[5] = lane_from_f(df[1], false);
+    g[0] = lane_from_f(g[4], true);
+    g[5] = lane_from_f(g[1], false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ix[j] = fmask(sm[j + 2] - sm[j], cm[j]);
+        iy[j] = fmask(__builtin_fmaf(2.0f, df[j + 1], df[j]) + df[j + 2], cm[j]);
+        it[j] = __builtin_fmaf(2.0f, g[j + 1], g[j]) + g[j + 2] - m.d[j];
+    }
+}
+
+__device__ __forceinline__ void derivs(const Row<OFX_MODE_COMPAT_CPU> &t, const Row<OFX_MODE_COMPAT_CPU> &m,
+                                       const Row<OFX_MODE_COMPAT_CPU> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
+                                       float (&it)[4])
+{
+    // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap contributes
+    // floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64).
+    // side[] = a column's contribution when it is left/right of the centre, mid[] when it is the centre column;
+    // bits 0..15 hold prev, bits 16..31 next (both halves stay < 256: no carry between them).
+    int sm[6], df[6], side[6], mid[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sm[j + 1] = t.p[j] + 2 * m.p[j] + b.p[j];
+        df[j + 1] = b.p[j] - t.p[j];
+        const int sp = (t.p[j] >> 4) + (m.p[j] >> 3) + (b.p[j] >> 4);
+        const int sn = (t.n[j] >> 4) + (m.n[j] >> 3) + (b.n[j] >> 4);
+        const int mp = (t.p[j] >> 3) + (m.p[j] >> 2) + (b.p[j] >> 3);
+        const int mn = (t.n[j] >> 3) + (m.n[j] >> 2) + (b.n[j] >> 3);
+        side[j + 1] = sp | (sn << 16);
+        mid[j] = mp | (mn << 16);
+    }
+    sm[0] = lane_from<-1>(sm[4]);
+    sm[5] = lane_from<1>(sm[1]);
+    df[0] = lane_from<-1>(df[4]);
+    df[5] = lane_from<1>(df[1]);
+    side[0] = lane_from<-1>(side[4]);
+    side[5] = lane_from<1>(side[1]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m8 = cm[j] & 0xff; // (unsigned char) wrap, OptFlowCPU.cpp:106
+        const int gsum = side[j] + mid[j] + side[j + 2];
+        ix[j] = (float)((sm[j + 2] - sm[j]) & m8);
+        iy[j] = (float)((df[j] + 2 * df[j + 1] + df[j + 2]) & m8);
+        it[j] = (float)(((gsum >> 16) - (gsum & 0xffff)) & 0xff); // It2 - It1 as unsigned char, OptFlowCPU.cpp:15,340
+    }
+}
+
+// a*b as an exact int32 through the fp32 pipe: for integer-valued |a*b| < 2^22, fma(a, b, 1.5*2^23) has the product
+// in its low mantissa bits, so bits(fma) - bits(1.5*2^23) == a*b.  (fma f32: 2 cycles; v_mul_i32_i24: 4.)
+#define OFX_MAGIC 12582912.0f
+#define OFX_MAGIC_BITS 0x4B400000
+
+template <bool HAVE_OUT>
+__device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&iy)[4], const float (&it)[4],
+                                           const float (&ox)[4], const float (&oy)[4], const float (&ot)[4], int (&vxx)[4],
+                                           int (&vyy)[4], int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
+{
+    // order of the planes: OptFlowCPU.cpp:347-358 / OptFlowGpu.cu:1948-1960
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int axx = __float_as_int(__builtin_fmaf(ix[j], ix[j], OFX_MAGIC));
+        const int ayy = __float_as_int(__builtin_fmaf(iy[j], iy[j], OFX_MAGIC));
+        const int axy = __float_as_int(__builtin_fmaf(ix[j], iy[j], OFX_MAGIC));
+        const int axt = __float_as_int(__builtin_fmaf(ix[j], it[j], OFX_MAGIC));
+        const int ayt = __float_as_int(__builtin_fmaf(iy[j], it[j], OFX_MAGIC));
+        int sxx = OFX_MAGIC_BITS, syy = OFX_MAGIC_BITS, sxy = OFX_MAGIC_BITS, sxt = OFX_MAGIC_BITS, syt = OFX_MAGIC_BITS;
+        if constexpr (HAVE_OUT) {
+            sxx = __float_as_int(__builtin_fmaf(ox[j], ox[j], OFX_MAGIC));
+            syy = __float_as_int(__builtin_fmaf(oy[j], oy[j], OFX_MAGIC));
+            sxy = __float_as_int(__builtin_fmaf(ox[j], oy[j], OFX_MAGIC));
+            sxt = __float_as_int(__builtin_fmaf(ox[j], ot[j], OFX_MAGIC));
+            syt = __float_as_int(__builtin_fmaf(oy[j], ot[j], OFX_MAGIC));
+        }
+        vxx[j] += axx - sxx;
+        vyy[j] += ayy - syy;
+        vxy[j] += axy - sxy;
+        vxt[j] += axt - sxt;
+        vyt[j] += ayt - syt;
+    }
+}
+
 template <int R, int MODE, bool SUMS>
 __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
-
-    // lane-private ring of the last NS derivative rows of this lane's 4 columns
-    __shared__ uint4 ring_a[NS * 64];
-    __shared__ uint2 ring_b[MODE == OFX_MODE_LK_FLOAT ? NS * 64 : 1];
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.x % A.tiles_x;
@@ -175,172 +344,89 @@ __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
     const int ys = A.out_y0 + strip * A.strip_h;
     const int ye = min(ys + A.strip_h, A.out_y1);
 
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        ring_a[s * 64 + lane] = make_uint4(0, 0, 0, 0);
-        if constexpr (MODE == OFX_MODE_LK_FLOAT) ring_b[s * 64 + lane] = make_uint2(0, 0);
-    }
-
     // column validity: bytes outside [0,w) read as zero, derivatives there are zero
     const bool ld_ok = cb >= 0 && cb < A.w;
     uint32_t bmask = 0;
-    int cv[4];
+    int cm[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const bool in = (cb + j) >= 0 && (cb + j) < A.w;
-        cv[j] = in ? -1 : 0;
+        cm[j] = in ? -1 : 0;
         bmask |= in ? (0xffu << (8 * j)) : 0u;
     }
-    const size_t col_off = ld_ok ? (size_t)cb : 0;
+    const uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
 
     // rows outside the image are the zero border; rows past the last one this strip needs (the loop prefetches one
-    // row ahead) or outside the buffer are never dereferenced
+    // row ahead) or outside the buffer are never dereferenced.  The row test is wave-uniform (scalar branch); lanes
+    // whose columns lie outside the image read column 0 of the row and are zeroed by bmask.
     const int y_lim = min(min(ye + R + 1, A.h), A.row_end);
     const int y_min = max(0, A.row0);
     auto load_row = [&](const uint8_t *img, int y) -> uint32_t {
-        if (y < y_min || y >= y_lim || !ld_ok) return 0u;
-        return *reinterpret_cast<const uint32_t *>(img + (size_t)(y - A.row0) * (size_t)A.pitch + col_off) & bmask;
+        uint32_t v = 0u;
+        if (y >= y_min && y < y_lim) {
+            const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch; // scalar
+            v = *reinterpret_cast<const uint32_t *>(row + col_off);
+        }
+        return v & bmask;
     };
 
-    // rolling 3-row windows (top, mid, bot) of both images, unpacked
-    int pt[4], pm[4], pb[4], nt[4], nm[4], nb[4];
+    // Two 3-row windows march down the strip NS rows apart: `in` around the derivative row entering the vertical
+    // window, `out` around the row leaving it.  The leaving row's derivatives are recomputed from the image (its rows
+    // are L2-resident: this wave read them NS steps ago) instead of being kept in an LDS ring: that costs one more
+    // derivative stage per step but no LDS, no pack/unpack of 16-bit fields, and it lets occupancy follow VGPRs only.
+    // Row r of either window lives in slot (r - (y_first - 1)) mod 3, so the loop is unrolled three times and every
+    // slot index is a compile-time constant (no register-to-register rotation).
     const int y_first = ys - R; // first derivative row this strip needs
-    unpack4(load_row(A.prev, y_first - 1), pm);
-    unpack4(load_row(A.next, y_first - 1), nm);
-    unpack4(load_row(A.prev, y_first), pb);
-    unpack4(load_row(A.next, y_first), nb);
-    uint32_t pf_p = load_row(A.prev, y_first + 1);
-    uint32_t pf_n = load_row(A.next, y_first + 1);
+    const int nsteps = (ye - ys) + 2 * R;
+    Row<MODE> win[3], wout[3];
+    {
+        const uint32_t p0 = load_row(A.prev, y_first - 1), n0 = load_row(A.next, y_first - 1);
+        const uint32_t p1 = load_row(A.prev, y_first), n1 = load_row(A.next, y_first);
+        unpack(p0, n0, win[0]);
+        unpack(p1, n1, win[1]);
+        wout[0] = win[0];
+        wout[1] = win[1];
+    }
+    uint32_t pf_ip = load_row(A.prev, y_first + 1), pf_in = load_row(A.next, y_first + 1);
+    uint32_t pf_op = pf_ip, pf_on = pf_in;
 
     int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
-    int slot = 0;
 
-    for (int yy = y_first; yy < ye + R; ++yy) {
-        // rotate the row windows and take the prefetched row; prefetch the next one
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pt[j] = pm[j];
-            pm[j] = pb[j];
-            nt[j] = nm[j];
-            nm[j] = nb[j];
-        }
-        unpack4(pf_p, pb);
-        unpack4(pf_n, nb);
-        pf_p = load_row(A.prev, yy + 2);
-        pf_n = load_row(A.next, yy + 2);
+    auto body = [&](auto K, int s) {
+        constexpr int k = decltype(K)::value;               // s mod 3
+        constexpr int ko = ((k - NS % 3) % 3 + 3) % 3;      // (s - NS) mod 3
+        const int yy = y_first + s;                         // derivative row entering the window
+        const int yo = yy - NS;                             // derivative row leaving it
+        const bool have_out = s >= NS;
 
-        const int rv = (yy >= 0 && yy < A.h) ? -1 : 0;
-
-        // ---- derivatives of row yy at this lane's 4 columns ------------------------------------------------
-        int ix[4], iy[4], it[4];
-        {
-            // vertical parts of the separable Sobel pair (kernels.cpp:6-19): sm = [1 2 1]^T, df = [-1 0 1]^T
-            int sm[6], df[6];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sm[j + 1] = pt[j] + 2 * pm[j] + pb[j];
-                df[j + 1] = pb[j] - pt[j];
-            }
-            sm[0] = lane_from<-1>(sm[4]);
-            sm[5] = lane_from<1>(sm[1]);
-            df[0] = lane_from<-1>(df[4]);
-            df[5] = lane_from<1>(df[1]);
-            if constexpr (MODE == OFX_MODE_LK_FLOAT) {
-                // It = Dt_3x3 (*) next - Dt_3x3 (*) prev (OptFlowGpu.cu:1936-1940) = Dt_3x3 (*) (next - prev), all
-                // exact integers.  Dt_3x3 = [1 2 1]^T[1 2 1] - centre (kernels.cpp:20-24).
-                int g[6], dm[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    dm[j] = nm[j] - pm[j];
-                    g[j + 1] = (nt[j] - pt[j]) + 2 * dm[j] + (nb[j] - pb[j]);
-                }
-                g[0] = lane_from<-1>(g[4]);
-                g[5] = lane_from<1>(g[1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = cv[j] & rv;
-                    ix[j] = (sm[j + 2] - sm[j]) & m;
-                    iy[j] = (df[j] + 2 * df[j + 1] + df[j + 2]) & m;
-                    it[j] = (g[j] + 2 * g[j + 1] + g[j + 2] - dm[j]) & m;
-                }
-            } else {
-                // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap
-                // contributes floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64).
-                // side[] = column contribution when the column is left/right of the centre, mid[] when it is the centre.
-                int side[6], mid[4]; // bits 0..15: prev, bits 16..31: next
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int sp = (pt[j] >> 4) + (pm[j] >> 3) + (pb[j] >> 4);
-                    const int sn = (nt[j] >> 4) + (nm[j] >> 3) + (nb[j] >> 4);
-                    const int mp = (pt[j] >> 3) + (pm[j] >> 2) + (pb[j] >> 3);
-                    const int mn = (nt[j] >> 3) + (nm[j] >> 2) + (nb[j] >> 3);
-                    side[j + 1] = sp | (sn << 16);
-                    mid[j] = mp | (mn << 16);
-                }
-                side[0] = lane_from<-1>(side[4]);
-                side[5] = lane_from<1>(side[1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int m = cv[j] & rv & 0xff; // (unsigned char) wrap, OptFlowCPU.cpp:106
-                    const int gsum = side[j] + mid[j] + side[j + 2]; // both halves < 256: no carry between them
-                    const int gp = gsum & 0xffff, gn = gsum >> 16;
-                    ix[j] = (sm[j + 2] - sm[j]) & m;
-                    iy[j] = (df[j] + 2 * df[j + 1] + df[j + 2]) & m;
-                    it[j] = (gn - gp) & m; // It2 - It1 as unsigned char, OptFlowCPU.cpp:15,340
-                }
-            }
+        // take the prefetched rows, prefetch the next ones (consumed one step from now)
+        unpack(pf_ip, pf_in, win[(k + 2) % 3]);
+        pf_ip = load_row(A.prev, yy + 2);
+        pf_in = load_row(A.next, yy + 2);
+        if (have_out) {
+            unpack(pf_op, pf_on, wout[(ko + 2) % 3]);
+            pf_op = load_row(A.prev, yo + 2);
+            pf_on = load_row(A.next, yo + 2);
         }
 
-        // ---- ring: fetch the row leaving the window (yy - NS), store the entering one ------------------------
-        int ox[4], oy[4], ot[4];
-        if constexpr (MODE == OFX_MODE_LK_FLOAT) {
-            const uint4 ra = ring_a[slot * 64 + lane];
-            const uint2 rb = ring_b[slot * 64 + lane];
-            const uint32_t w4[4] = {ra.x, ra.y, ra.z, ra.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ox[j] = (int)(short)(w4[j] & 0xffff);
-                oy[j] = (int)w4[j] >> 16;
-            }
-            ot[0] = (int)(short)(rb.x & 0xffff);
-            ot[1] = (int)rb.x >> 16;
-            ot[2] = (int)(short)(rb.y & 0xffff);
-            ot[3] = (int)rb.y >> 16;
-            ring_a[slot * 64 + lane] = make_uint4(((uint32_t)ix[0] & 0xffff) | ((uint32_t)iy[0] << 16),
-                                                  ((uint32_t)ix[1] & 0xffff) | ((uint32_t)iy[1] << 16),
-                                                  ((uint32_t)ix[2] & 0xffff) | ((uint32_t)iy[2] << 16),
-                                                  ((uint32_t)ix[3] & 0xffff) | ((uint32_t)iy[3] << 16));
-            ring_b[slot * 64 + lane] = make_uint2(((uint32_t)it[0] & 0xffff) | ((uint32_t)it[1] << 16),
-                                                  ((uint32_t)it[2] & 0xffff) | ((uint32_t)it[3] << 16));
+        float ix[4], iy[4], it[4];
+        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182)
+        const int rvi = (yy >= 0 && yy < A.h) ? -1 : 0;
+        const int cmi[4] = {cm[0] & rvi, cm[1] & rvi, cm[2] & rvi, cm[3] & rvi};
+        derivs(win[k], win[(k + 1) % 3], win[(k + 2) % 3], cmi, ix, iy, it);
+        if (have_out) {
+            float ox[4], oy[4], ot[4];
+            const int rvo = (yo >= 0 && yo < A.h) ? -1 : 0;
+            const int cmo[4] = {cm[0] & rvo, cm[1] & rvo, cm[2] & rvo, cm[3] & rvo};
+            derivs(wout[ko], wout[(ko + 1) % 3], wout[(ko + 2) % 3], cmo, ox, oy, ot);
+            accumulate<true>(ix, iy, it, ox, oy, ot, vxx, vyy, vxy, vxt, vyt);
         } else {
-            const uint4 ra = ring_a[slot * 64 + lane];
-            const uint32_t w4[4] = {ra.x, ra.y, ra.z, ra.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ox[j] = w4[j] & 0xff;
-                oy[j] = (w4[j] >> 8) & 0xff;
-                ot[j] = (w4[j] >> 16) & 0xff;
-            }
-            ring_a[slot * 64 + lane] = make_uint4((uint32_t)ix[0] | ((uint32_t)iy[0] << 8) | ((uint32_t)it[0] << 16),
-                                                  (uint32_t)ix[1] | ((uint32_t)iy[1] << 8) | ((uint32_t)it[1] << 16),
-                                                  (uint32_t)ix[2] | ((uint32_t)iy[2] << 8) | ((uint32_t)it[2] << 16),
-                                                  (uint32_t)ix[3] | ((uint32_t)iy[3] << 8) | ((uint32_t)it[3] << 16));
-        }
-        slot = (slot + 1 == NS) ? 0 : slot + 1;
-
-        // ---- vertical running sums of the five products (OptFlowCPU.cpp:347-358 order: xx, yy, xy, xt, yt) ----
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            vxx[j] += ix[j] * ix[j] - ox[j] * ox[j];
-            vyy[j] += iy[j] * iy[j] - oy[j] * oy[j];
-            vxy[j] += ix[j] * iy[j] - ox[j] * oy[j];
-            vxt[j] += ix[j] * it[j] - ox[j] * ot[j];
-            vyt[j] += iy[j] * it[j] - oy[j] * ot[j];
+            accumulate<false>(ix, iy, it, ix, iy, it, vxx, vyy, vxy, vxt, vyt);
         }
 
-        // ---- emit output row y = yy - R ----------------------------------------------------------------------
-        const int y = yy - R;
-        if (y >= ys) {
+        // ---- emit output row y = yy - R ------------------------------------------------------------------------
+        if (s >= 2 * R) {
+            const int y = yy - R;
             int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
             hbox4<R>(vxx, hxx);
             hbox4<R>(vyy, hyy);
@@ -349,7 +435,8 @@ __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
             hbox4<R>(vyt, hyt);
             const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
             if (out_lane) {
-                const size_t pix = (size_t)(y - A.flow_row0) * (size_t)A.w + (size_t)cb;
+                const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
+                const size_t pix = rowpix + (uint32_t)cb;
                 if constexpr (SUMS) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -365,7 +452,7 @@ __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
                     float uv[8];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
-                    float *dst = A.flow + 2 * pix;
+                    float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
                     if (cb + 3 < A.w) {
                         // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
                         float2 *d2 = reinterpret_cast<float2 *>(dst);
@@ -384,6 +471,16 @@ __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
                 }
             }
         }
+    };
+
+    int s = 0;
+    while (true) {
+        body(std::integral_constant<int, 0>{}, s);
+        if (++s >= nsteps) break;
+        body(std::integral_constant<int, 1>{}, s);
+        if (++s >= nsteps) break;
+        body(std::integral_constant<int, 2>{}, s);
+        if (++s >= nsteps) break;
     }
 }
 
@@ -395,10 +492,17 @@ int launch_r(const LkArgs &base, int rows_out, hipStream_t st)
     a.tiles_x = ofx_div_up(a.w, G::OUT_W);
     // enough single-wave workgroups to give every SIMD a few waves, but strips tall enough that the 2R priming
     // rows (derivatives + vertical sums only, no solve/store) stay a small fraction
-    const int target_waves = 4096;
+    static const int target_waves = [] {
+        const char *e = getenv("OFX_LK_TARGET_WAVES");
+        return e && atoi(e) > 0 ? atoi(e) : 4096;
+    }();
     int strips = ofx_div_up(target_waves, a.tiles_x);
     int strip_h = ofx_div_up(rows_out, strips);
-    const int min_h = 2 * R > 8 ? 2 * R : 8;
+    static const int min_env = [] {
+        const char *e = getenv("OFX_LK_MIN_STRIP");
+        return e && atoi(e) > 0 ? atoi(e) : 0;
+    }();
+    const int min_h = min_env ? min_env : (2 * R > 8 ? 2 * R : 8);
     if (strip_h < min_h) strip_h = min_h;
     if (strip_h > rows_out) strip_h = rows_out;
     strips = ofx_div_up(rows_out, strip_h);
