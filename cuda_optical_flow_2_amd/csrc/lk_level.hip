@@ -24,6 +24,7 @@
 
 #include <type_traits>
 
+#include "lk_solve.h"
 #include "ofx_internal.h"
 
 namespace {
@@ -37,6 +38,13 @@ struct LkArgs {
     int w, h, pitch, row0, row_end; // buffer holds global rows [row0,row_end)
     int out_y0, out_y1, flow_row0;
     int strip_h, tiles_x;
+};
+
+// one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
+struct LkTable {
+    LkArgs lv[OFX_MAX_LEVELS];
+    int first_block[OFX_MAX_LEVELS + 1];
+    int n;
 };
 
 // value of x held by lane (lane + D); 0 where that lane does not exist.  gfx9 DPP whole-wave shifts.
@@ -128,55 +136,6 @@ __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
     out[1] = hbox_one<R, 1>(q, s);
     out[2] = hbox_one<R, 2>(q, s);
     out[3] = hbox_one<R, 3>(q, s);
-}
-
-// ---- 2x2 solve ---------------------------------------------------------------------------------------------
-// MODE 1: gpu::inverse_matrix_float, OptFlowGpu.cu:1833-1845 -- the sums are float planes there, so each exact
-//         integer sum is rounded once to float first.
-// MODE 0: inline loop of cpu::calc_optical_flow, OptFlowCPU.cpp:369-382 -- int sums, `c` left unscaled.
-// Same operation order as the reference, in double, with IEEE division; this file is built with
-// -ffp-contract=off so no product/sum pair is fused.
-// 1/x in double, x an integer-valued double of moderate magnitude (|x| < 2^57, no subnormals involved).
-// v_rcp_f64 seed, one Newton step to ~1 ulp, then Markstein's correction r = fma(-x,p,1); p = fma(p,r,p), which
-// yields the correctly rounded quotient (the only exception, an all-ones significand, needs |x| >= 2^52).  x == 0
-// gives +-Inf like the IEEE division the reference performs.  8 instructions instead of the ~13 of the generic
-// division expansion (div_scale/div_fmas/div_fixup handle ranges that cannot occur here).
-__device__ __forceinline__ double recip_f64(double x)
-{
-    double p = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, p, 1.0);
-    p = __builtin_fma(p, e, p);
-    e = __builtin_fma(-x, p, 1.0);
-    p = __builtin_fma(p, e, p);
-    e = __builtin_fma(-x, p, 1.0);
-    p = __builtin_fma(p, e, p);
-    return x == 0.0 ? __builtin_copysign(__builtin_inf(), x) : p;
-}
-
-template <int MODE>
-__device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int syt, float &u, float &v)
-{
-    double a, b, c, d, xt, yt;
-    if constexpr (MODE == OFX_MODE_LK_FLOAT) {
-        a = (double)(float)sxx;
-        b = c = (double)(float)sxy;
-        d = (double)(float)syy;
-        xt = (double)(float)sxt;
-        yt = (double)(float)syt;
-    } else {
-        a = (double)sxx;
-        b = c = (double)sxy;
-        d = (double)syy;
-        xt = (double)sxt;
-        yt = (double)syt;
-    }
-    const double pre = recip_f64(a * d - b * c);
-    a *= pre;
-    b *= pre;
-    if constexpr (MODE == OFX_MODE_LK_FLOAT) c *= pre;
-    d *= pre;
-    u = (float)(-d * xt + b * yt);
-    v = (float)(c * xt - a * yt);
 }
 
 // geometry of a wave tile for radius R (also used by the host)
@@ -331,15 +290,22 @@ __device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&i
     }
 }
 
+#ifndef OFX_LK_WAVES_PER_SIMD
+#define OFX_LK_WAVES_PER_SIMD 1
+#endif
 template <int R, int MODE, bool SUMS>
-__global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
+__global__ __launch_bounds__(64, OFX_LK_WAVES_PER_SIMD) void lk_level_kernel(const LkTable T)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
 
+    int level = 0;
+    while (level + 1 < T.n && (int)blockIdx.x >= T.first_block[level + 1]) ++level;
+    const LkArgs &A = T.lv[level];
+    const int block = (int)blockIdx.x - T.first_block[level];
     const int lane = threadIdx.x;
-    const int tile = blockIdx.x % A.tiles_x;
-    const int strip = blockIdx.x / A.tiles_x;
+    const int tile = block % A.tiles_x;
+    const int strip = block / A.tiles_x;
     const int cb = tile * G::OUT_W - G::LO_LANE * 4 + 4 * lane; // first of this lane's 4 image columns
     const int ys = A.out_y0 + strip * A.strip_h;
     const int ye = min(ys + A.strip_h, A.out_y1);
@@ -484,108 +450,149 @@ __global__ __launch_bounds__(64) void lk_level_kernel(const LkArgs A)
     }
 }
 
+// ---- host side ----------------------------------------------------------------------------------------------------
+struct LkLevelIn {
+    LkArgs a;     // everything but strip_h / tiles_x
+    int rows_out;
+};
+
+int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
+
 template <int R, int MODE, bool SUMS>
-int launch_r(const LkArgs &base, int rows_out, hipStream_t st)
+int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
     using G = TileGeom<R>;
-    LkArgs a = base;
-    a.tiles_x = ofx_div_up(a.w, G::OUT_W);
-    // enough single-wave workgroups to give every SIMD a few waves, but strips tall enough that the 2R priming
-    // rows (derivatives + vertical sums only, no solve/store) stay a small fraction
-    static const int target_waves = [] {
-        const char *e = getenv("OFX_LK_TARGET_WAVES");
-        return e && atoi(e) > 0 ? atoi(e) : 4096;
+    // Waves that can be resident at once.  The grid is sized to fit in ONE round: every wave runs for the whole
+    // kernel, so a second, partly filled round would nearly double the run time.
+    static const int capacity = [] {
+        int dev = 0, cus = 256, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lk_level_kernel<R, MODE, SUMS>, 64, 0) != hipSuccess || per_cu <= 0)
+            per_cu = 8;
+        (void)hipGetLastError();
+        return env_int("OFX_LK_TARGET_WAVES", cus * per_cu);
     }();
-    int strips = ofx_div_up(target_waves, a.tiles_x);
-    int strip_h = ofx_div_up(rows_out, strips);
-    static const int min_env = [] {
-        const char *e = getenv("OFX_LK_MIN_STRIP");
-        return e && atoi(e) > 0 ? atoi(e) : 0;
-    }();
-    const int min_h = min_env ? min_env : (2 * R > 8 ? 2 * R : 8);
-    if (strip_h < min_h) strip_h = min_h;
-    if (strip_h > rows_out) strip_h = rows_out;
-    strips = ofx_div_up(rows_out, strip_h);
-    a.strip_h = strip_h;
-    const unsigned grid = (unsigned)(a.tiles_x * strips);
-    hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3(grid), dim3(64), 0, st, a);
+    // One strip height for all levels (so all waves run about equally long): the smallest that keeps the wave count
+    // within ~95% of capacity, but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
+    const int min_h = env_int("OFX_LK_MIN_STRIP", 8);
+    int max_rows = 1;
+    for (int i = 0; i < n; ++i) max_rows = lv[i].rows_out > max_rows ? lv[i].rows_out : max_rows;
+    int strip_h = min_h;
+    for (; strip_h < max_rows; ++strip_h) {
+        long waves = 0;
+        for (int i = 0; i < n; ++i) waves += (long)ofx_div_up(lv[i].a.w, G::OUT_W) * ofx_div_up(lv[i].rows_out, strip_h);
+        if (waves * 100 <= (long)capacity * 95) break;
+    }
+    LkTable t{};
+    t.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        t.lv[i] = lv[i].a;
+        t.lv[i].tiles_x = ofx_div_up(lv[i].a.w, G::OUT_W);
+        t.lv[i].strip_h = strip_h < lv[i].rows_out ? strip_h : lv[i].rows_out;
+        t.first_block[i] = blocks;
+        blocks += t.lv[i].tiles_x * ofx_div_up(lv[i].rows_out, t.lv[i].strip_h);
+    }
+    t.first_block[n] = blocks;
+    hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3((unsigned)blocks), dim3(64), 0, st, t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
 template <int MODE, bool SUMS>
-int launch_mode(int radius, const LkArgs &a, int rows_out, hipStream_t st)
+int launch_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_r<1, MODE, SUMS>(a, rows_out, st);
-    case 2: return launch_r<2, MODE, SUMS>(a, rows_out, st);
-    case 3: return launch_r<3, MODE, SUMS>(a, rows_out, st);
-    case 4: return launch_r<4, MODE, SUMS>(a, rows_out, st);
-    case 5: return launch_r<5, MODE, SUMS>(a, rows_out, st);
-    case 6: return launch_r<6, MODE, SUMS>(a, rows_out, st);
-    case 7: return launch_r<7, MODE, SUMS>(a, rows_out, st);
-    case 8: return launch_r<8, MODE, SUMS>(a, rows_out, st);
-    case 9: return launch_r<9, MODE, SUMS>(a, rows_out, st);
-    case 10: return launch_r<10, MODE, SUMS>(a, rows_out, st);
-    case 11: return launch_r<11, MODE, SUMS>(a, rows_out, st);
+    case 1: return launch_r<1, MODE, SUMS>(lv, n, st);
+    case 2: return launch_r<2, MODE, SUMS>(lv, n, st);
+    case 3: return launch_r<3, MODE, SUMS>(lv, n, st);
+    case 4: return launch_r<4, MODE, SUMS>(lv, n, st);
+    case 5: return launch_r<5, MODE, SUMS>(lv, n, st);
+    case 6: return launch_r<6, MODE, SUMS>(lv, n, st);
+    case 7: return launch_r<7, MODE, SUMS>(lv, n, st);
+    case 8: return launch_r<8, MODE, SUMS>(lv, n, st);
+    case 9: return launch_r<9, MODE, SUMS>(lv, n, st);
+    case 10: return launch_r<10, MODE, SUMS>(lv, n, st);
+    case 11: return launch_r<11, MODE, SUMS>(lv, n, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_r<12, MODE, SUMS>(a, rows_out, st);
+        if (radius == 12) return launch_r<12, MODE, SUMS>(lv, n, st);
     }
     ofx_set_error("ofx_lk_level: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
 }
 
-int lk_dispatch(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode, float *d_flow,
-                int32_t *d_sums, int flow_row0, void *stream)
+int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, void *stream)
 {
-    OFX_TRY(ofx_check_geom(g, "ofx_lk_level"));
-    OFX_REQUIRE(d_prev && d_next && (d_flow || d_sums), "ofx_lk_level: null pointer");
+    OFX_REQUIRE(d != nullptr && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_lk_levels: bad descriptor count %d", n);
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_lk_level: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_lk_level: bad mode %d", mode);
-    OFX_REQUIRE(((uintptr_t)d_prev & 3) == 0 && ((uintptr_t)d_next & 3) == 0, "ofx_lk_level: planes must be 4-byte aligned");
-    OFX_REQUIRE(flow_row0 <= g->out_y0, "ofx_lk_level: flow_row0 %d > out_y0 %d", flow_row0, g->out_y0);
     const int radius = window >> 1;
-    OFX_TRY(ofx_check_halo(g, radius + 1, "ofx_lk_level"));
-    const int rows_out = g->out_y1 - g->out_y0;
-    if (rows_out <= 0) return OFX_OK;
-    LkArgs a{};
-    a.prev = d_prev;
-    a.next = d_next;
-    a.flow = d_flow;
-    a.sums = d_sums;
-    a.w = g->w;
-    a.h = g->h;
-    a.pitch = g->pitch;
-    a.row0 = g->row0;
-    a.row_end = g->row0 + g->rows;
-    a.out_y0 = g->out_y0;
-    a.out_y1 = g->out_y1;
-    a.flow_row0 = flow_row0;
+    LkLevelIn lv[OFX_MAX_LEVELS];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const ofx_geom *g = &d[i].geom;
+        OFX_TRY(ofx_check_geom(g, "ofx_lk_level"));
+        OFX_REQUIRE(d[i].d_prev && d[i].d_next && (d[i].d_flow || d_sums), "ofx_lk_level: null pointer");
+        OFX_REQUIRE(((uintptr_t)d[i].d_prev & 3) == 0 && ((uintptr_t)d[i].d_next & 3) == 0, "ofx_lk_level: planes must be 4-byte aligned");
+        OFX_REQUIRE(d[i].flow_row0 <= g->out_y0, "ofx_lk_level: flow_row0 %d > out_y0 %d", d[i].flow_row0, g->out_y0);
+        OFX_TRY(ofx_check_halo(g, radius + 1, "ofx_lk_level"));
+        const int rows_out = g->out_y1 - g->out_y0;
+        if (rows_out <= 0) continue;
+        LkArgs a{};
+        a.prev = d[i].d_prev;
+        a.next = d[i].d_next;
+        a.flow = d[i].d_flow;
+        a.sums = d_sums;
+        // plane stride of the inspection output = rows from flow_row0 to out_y1
+        a.sums_plane = (size_t)(g->out_y1 - d[i].flow_row0) * (size_t)g->w;
+        a.w = g->w;
+        a.h = g->h;
+        a.pitch = g->pitch;
+        a.row0 = g->row0;
+        a.row_end = g->row0 + g->rows;
+        a.out_y0 = g->out_y0;
+        a.out_y1 = g->out_y1;
+        a.flow_row0 = d[i].flow_row0;
+        lv[m].a = a;
+        lv[m].rows_out = rows_out;
+        ++m;
+    }
+    if (m == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
     if (d_sums) {
-        // plane stride of the inspection output = rows from flow_row0 to out_y1
-        a.sums_plane = (size_t)(g->out_y1 - flow_row0) * (size_t)g->w;
-        return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, true>(radius, a, rows_out, st)
-                                         : launch_mode<OFX_MODE_COMPAT_CPU, true>(radius, a, rows_out, st);
+        return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, true>(radius, lv, m, st)
+                                         : launch_mode<OFX_MODE_COMPAT_CPU, true>(radius, lv, m, st);
     }
-    return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, false>(radius, a, rows_out, st)
-                                     : launch_mode<OFX_MODE_COMPAT_CPU, false>(radius, a, rows_out, st);
+    return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, false>(radius, lv, m, st)
+                                     : launch_mode<OFX_MODE_COMPAT_CPU, false>(radius, lv, m, st);
 }
 
 } // namespace
 
+extern "C" int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream)
+{
+    return lk_dispatch(levels, n, window, mode, nullptr, stream);
+}
+
 extern "C" int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
                             float *d_flow, int flow_row0, void *stream)
 {
-    OFX_REQUIRE(d_flow, "ofx_lk_level: d_flow is null");
-    return lk_dispatch(d_prev, d_next, g, window, mode, d_flow, nullptr, flow_row0, stream);
+    OFX_REQUIRE(d_flow && g, "ofx_lk_level: null argument");
+    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0};
+    return lk_dispatch(&d, 1, window, mode, nullptr, stream);
 }
 
 extern "C" int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
                                  int32_t *d_sums5, int flow_row0, void *stream)
 {
-    OFX_REQUIRE(d_sums5, "ofx_lk_level_sums: d_sums5 is null");
-    return lk_dispatch(d_prev, d_next, g, window, mode, nullptr, d_sums5, flow_row0, stream);
+    OFX_REQUIRE(d_sums5 && g, "ofx_lk_level_sums: null argument");
+    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0};
+    return lk_dispatch(&d, 1, window, mode, d_sums5, stream);
 }

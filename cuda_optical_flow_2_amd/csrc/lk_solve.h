@@ -1,0 +1,57 @@
+// The per-pixel 2x2 solve shared by the fused level kernel and the corner kernel (both must produce bit-identical
+// flow for pixel 0 of a level).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ofx.h"
+
+// ---- 2x2 solve ---------------------------------------------------------------------------------------------
+// MODE 1: gpu::inverse_matrix_float, OptFlowGpu.cu:1833-1845 -- the sums are float planes there, so each exact
+//         integer sum is rounded once to float first.
+// MODE 0: inline loop of cpu::calc_optical_flow, OptFlowCPU.cpp:369-382 -- int sums, `c` left unscaled.
+// Same operation order as the reference, in double, with IEEE division; this file is built with
+// -ffp-contract=off so no product/sum pair is fused.
+// 1/x in double, x an integer-valued double of moderate magnitude (|x| < 2^57, no subnormals involved).
+// v_rcp_f64 seed, one Newton step to ~1 ulp, then Markstein's correction r = fma(-x,p,1); p = fma(p,r,p), which
+// yields the correctly rounded quotient (the only exception, an all-ones significand, needs |x| >= 2^52).  x == 0
+// gives +-Inf like the IEEE division the reference performs.  8 instructions instead of the ~13 of the generic
+// division expansion (div_scale/div_fmas/div_fixup handle ranges that cannot occur here).
+__device__ __forceinline__ double recip_f64(double x)
+{
+    double p = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    e = __builtin_fma(-x, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    return x == 0.0 ? __builtin_copysign(__builtin_inf(), x) : p;
+}
+
+template <int MODE>
+__device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int syt, float &u, float &v)
+{
+    double a, b, c, d, xt, yt;
+    if constexpr (MODE == OFX_MODE_LK_FLOAT) {
+        a = (double)(float)sxx;
+        b = c = (double)(float)sxy;
+        d = (double)(float)syy;
+        xt = (double)(float)sxt;
+        yt = (double)(float)syt;
+    } else {
+        a = (double)sxx;
+        b = c = (double)sxy;
+        d = (double)syy;
+        xt = (double)sxt;
+        yt = (double)syt;
+    }
+    const double pre = recip_f64(a * d - b * c);
+    a *= pre;
+    b *= pre;
+    if constexpr (MODE == OFX_MODE_LK_FLOAT) c *= pre;
+    d *= pre;
+    u = (float)(-d * xt + b * yt);
+    v = (float)(c * xt - a * yt);
+}
+

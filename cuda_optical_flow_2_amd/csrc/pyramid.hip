@@ -113,13 +113,24 @@ struct ShiftArgs {
     const uint8_t *src;
     uint8_t *dst;
     const float *uv;
-    int w, h, pitch, row0, row_end, out_y0, out_y1;
+    int w, h, pitch, row0, row_end, out_y0, out_y1, blocks_x;
 };
 
-__global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftArgs A)
+struct ShiftTable {
+    ShiftArgs lv[OFX_MAX_LEVELS];
+    int first_block[OFX_MAX_LEVELS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftTable T)
 {
-    const int x0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
-    const int y = A.out_y0 + blockIdx.y;
+    int level = 0;
+    while (level + 1 < T.n && (int)blockIdx.x >= T.first_block[level + 1]) ++level;
+    const ShiftArgs &A = T.lv[level];
+    const int block = (int)blockIdx.x - T.first_block[level];
+    const int bx = block % A.blocks_x, by = block / A.blocks_x;
+    const int x0 = 4 * (bx * (int)blockDim.x + (int)threadIdx.x);
+    const int y = A.out_y0 + by;
     if (x0 >= A.pitch || y >= A.out_y1) return;
     const float u = A.uv[0], v = A.uv[1];
     const float ty = (float)y + v;
@@ -250,18 +261,38 @@ extern "C" int ofx_shift_vector(const float *const *d_flow_levels, int level, in
     return OFX_OK;
 }
 
-extern "C" int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream)
+extern "C" int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream)
 {
-    OFX_TRY(ofx_check_geom(g, "ofx_shift_1ch"));
-    OFX_REQUIRE(d_src && d_dst && d_uv, "ofx_shift_1ch: null pointer");
-    OFX_REQUIRE(d_src != d_dst, "ofx_shift_1ch: in-place shift is not supported");
-    OFX_REQUIRE(g->out_y0 >= g->row0 && g->out_y1 <= g->row0 + g->rows, "ofx_shift_1ch: output rows outside the buffer");
-    if (g->out_y1 <= g->out_y0) return OFX_OK;
-    ShiftArgs a{d_src, d_dst, d_uv, g->w, g->h, g->pitch, g->row0, g->row0 + g->rows, g->out_y0, g->out_y1};
-    dim3 grid(ofx_div_up(g->pitch / 4, 256), g->out_y1 - g->out_y0);
-    hipLaunchKernelGGL(shift_1ch_kernel, grid, dim3(256), 0, ofx_stream(stream), a);
+    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_shift_levels: bad descriptor count %d", n);
+    ShiftTable t{};
+    int blocks = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const ofx_geom *g = &levels[i].geom;
+        OFX_TRY(ofx_check_geom(g, "ofx_shift_1ch"));
+        OFX_REQUIRE(levels[i].d_src && levels[i].d_dst && levels[i].d_uv, "ofx_shift_1ch: null pointer");
+        OFX_REQUIRE(levels[i].d_src != levels[i].d_dst, "ofx_shift_1ch: in-place shift is not supported");
+        OFX_REQUIRE(g->out_y0 >= g->row0 && g->out_y1 <= g->row0 + g->rows, "ofx_shift_1ch: output rows outside the buffer");
+        if (g->out_y1 <= g->out_y0) continue;
+        const int bx = ofx_div_up(g->pitch / 4, 256);
+        t.lv[m] = ShiftArgs{levels[i].d_src, levels[i].d_dst, levels[i].d_uv, g->w, g->h, g->pitch, g->row0, g->row0 + g->rows,
+                            g->out_y0, g->out_y1, bx};
+        t.first_block[m] = blocks;
+        blocks += bx * (g->out_y1 - g->out_y0);
+        ++m;
+    }
+    if (m == 0) return OFX_OK;
+    t.n = m;
+    t.first_block[m] = blocks;
+    hipLaunchKernelGGL(shift_1ch_kernel, dim3((unsigned)blocks), dim3(256), 0, ofx_stream(stream), t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
+}
+
+extern "C" int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream)
+{
+    OFX_REQUIRE(g != nullptr, "ofx_shift_1ch: geometry is null");
+    ofx_shift_desc d{d_src, d_dst, *g, d_uv};
+    return ofx_shift_levels(&d, 1, stream);
 }
 
 extern "C" int ofx_compose_flow(const float *const *d_flow_levels, int w, int h, int levels, int level, float *d_dst,

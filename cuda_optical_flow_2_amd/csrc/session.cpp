@@ -275,9 +275,67 @@ extern "C" int ofx_session_timing_read(ofx_session *s, double *avg_us, double *m
     return OFX_OK;
 }
 
+// Shift vectors of every level at once (ofx_corner_flows); meaningful on the rank whose buffers start at row 0.
+extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_corner_flows: null session");
+    if (!s->have_prev || !s->have_next) {
+        ofx_set_error("ofx_session_corner_flows: need a previous and a next frame");
+        return OFX_E_STATE;
+    }
+    ofx_lk_desc d[OFX_MAX_LEVELS];
+    for (int k = 0; k < s->p.levels; ++k)
+        d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k]};
+    return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv, stream);
+}
+
+// Every level's shift in one launch, then every level's fused LK in one launch, using the uv slots as they stand.
+extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_run_levels: null session");
+    if (!s->have_prev || !s->have_next) {
+        ofx_set_error("ofx_session_run_levels: need a previous and a next frame");
+        return OFX_E_STATE;
+    }
+    const int L = s->p.levels, halo = (s->p.window >> 1) + 1;
+    ofx_shift_desc sh[OFX_MAX_LEVELS];
+    ofx_lk_desc lk[OFX_MAX_LEVELS];
+    int ns = 0, nl = 0;
+    for (int k = L - 1; k >= 0; --k) { // coarse levels first: their few waves start at once and finish early
+        const uint8_t *next = s->plane[1][k];
+        if (k != L - 1) {
+            int y0 = s->own0[k] - halo, y1 = s->own1[k] + halo;
+            if (y0 < s->buf0[k]) y0 = s->buf0[k];
+            if (y1 > s->buf1[k]) y1 = s->buf1[k];
+            sh[ns++] = ofx_shift_desc{s->plane[1][k], s->plane[2][k], level_geom(s, k, y0, y1), s->uv + 2 * k};
+            next = s->plane[2][k];
+        }
+        lk[nl++] = ofx_lk_desc{s->plane[0][k], next, level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k]};
+    }
+    if (ns) OFX_TRY(ofx_shift_levels(sh, ns, stream));
+    const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
+    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
+    OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+    if (timed) {
+        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
+        s->ev_used += 2;
+    }
+    return OFX_OK;
+}
+
 extern "C" int ofx_session_run_flow(ofx_session *s, void *stream)
 {
     OFX_REQUIRE(s, "ofx_session_run_flow: null session");
+    OFX_REQUIRE(!s->p.sharded || s->buf0[0] == 0, "ofx_session_run_flow: on a sharded session only the rank holding row 0 can "
+                                                   "form the shift vectors; use corner_flows + broadcast + run_levels");
+    OFX_TRY(ofx_session_corner_flows(s, stream));
+    return ofx_session_run_levels(s, stream);
+}
+
+// The reference's literal sequence (one level after the other, main.cu:256-262); kept for comparison and tests.
+extern "C" int ofx_session_run_flow_sequential(ofx_session *s, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_run_flow_sequential: null session");
     for (int k = s->p.levels - 1; k >= 0; --k) {
         OFX_TRY(ofx_session_compute_uv(s, k, stream));
         OFX_TRY(ofx_session_run_level(s, k, stream));

@@ -100,6 +100,15 @@ class Session:
     def run_flow(self, stream=None):
         check(self.L.ofx_session_run_flow(self._h, _stream_ptr(stream)), "run_flow")
 
+    def run_flow_sequential(self, stream=None):
+        check(self.L.ofx_session_run_flow_sequential(self._h, _stream_ptr(stream)), "run_flow_sequential")
+
+    def corner_flows(self, stream=None):
+        check(self.L.ofx_session_corner_flows(self._h, _stream_ptr(stream)), "corner_flows")
+
+    def run_levels(self, stream=None):
+        check(self.L.ofx_session_run_levels(self._h, _stream_ptr(stream)), "run_levels")
+
     def compute_uv(self, level: int, stream=None):
         check(self.L.ofx_session_compute_uv(self._h, level, _stream_ptr(stream)), "compute_uv")
 

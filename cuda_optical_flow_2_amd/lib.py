@@ -48,6 +48,9 @@ _SIGS = {
     "ofx_abi_version": [],
     "ofx_device_count": [],
     "ofx_lk_level": [_vp, _vp, _gp, _i, _i, _vp, _i, _vp],
+    "ofx_lk_levels": [_vp, _i, _i, _i, _vp],
+    "ofx_corner_flows": [_vp, _i, _i, _i, _vp, _vp],
+    "ofx_shift_levels": [_vp, _i, _vp],
     "ofx_lk_level_sums": [_vp, _vp, _gp, _i, _i, _vp, _i, _vp],
     "ofx_downsample_1ch": [_vp, _i, _i, _i, _vp, _gp, _vp],
     "ofx_shift_vector": [C.POINTER(_vp), _i, _i, _vp, _vp],
@@ -74,6 +77,9 @@ _SIGS = {
     "ofx_session_build_pyramid": [_vp, _vp],
     "ofx_session_downsample_level": [_vp, _i, _vp],
     "ofx_session_run_flow": [_vp, _vp],
+    "ofx_session_corner_flows": [_vp, _vp],
+    "ofx_session_run_levels": [_vp, _vp],
+    "ofx_session_run_flow_sequential": [_vp, _vp],
     "ofx_session_compute_uv": [_vp, _i, _vp],
     "ofx_session_run_level": [_vp, _i, _vp],
     "ofx_session_swap": [_vp],

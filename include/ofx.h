@@ -82,6 +82,17 @@ typedef struct ofx_geom {
 int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
                  float *d_flow, int flow_row0, void *stream);
 
+/* Several levels in ONE launch (the levels of a pyramid are independent once the shift vectors are known -- see
+ * ofx_corner_flows).  Descriptors are processed in the order given; coarse levels first is the useful order. */
+typedef struct ofx_lk_desc {
+    const uint8_t *d_prev;
+    const uint8_t *d_next; /* already shifted below the top level */
+    ofx_geom geom;
+    float *d_flow;
+    int flow_row0;
+} ofx_lk_desc;
+int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
+
 /* Same level, but stopping before the solve: writes the five window sums
  * (Sxx, Syy, Sxy, Sxt, Syt) as int32 planes of w ints per row.  Test/inspection
  * entry point; equals five gpu::srm_1ch(_float) calls (OptFlowGpu.cu:1944-1960). */
@@ -103,6 +114,23 @@ int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_row0, int sr
  * d_flow_levels[k] = device pointer to level k's flow (only k > level are read).
  * Writes 2 floats to d_uv. */
 int ofx_shift_vector(const float *const *d_flow_levels, int level, int max_level, float *d_uv, void *stream);
+
+/* The shift of level k only needs PIXEL 0 of every coarser flow level (OptFlowCPU.cpp:260-262), and pixel 0's flow
+ * only needs the (radius+2)^2 top-left corner of its level.  This entry point walks the pyramid coarse to fine in
+ * one tiny launch: for each level it forms the shift vector from the corner flows found so far, evaluates pixel 0's
+ * window sums on the shifted corner, solves, and stores d_uv[2k..2k+1] (and flow level k's pixel 0 when the
+ * descriptor's flow_row0 is 0).  After it every level's shift and LK launch is independent of the others.
+ * Descriptors: index k = pyramid level k, d_next = the UNSHIFTED next plane, geom.row0 must be 0. */
+int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, void *stream);
+
+/* Several ofx_shift_1ch calls in one launch. */
+typedef struct ofx_shift_desc {
+    const uint8_t *d_src;
+    uint8_t *d_dst;
+    ofx_geom geom;
+    const float *d_uv;
+} ofx_shift_desc;
+int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream);
 
 /* dst(x,y) = src((int)(x+u), (int)(y+v)) when that lands inside the image,
  * else src(x,y) if 3*(y*w+x) < w*h else 0 -- cpu::shift_back_pyramid
@@ -187,9 +215,13 @@ int ofx_session_set_frame_device(ofx_session *s, const uint8_t *d_gray1, int pit
 int ofx_session_build_pyramid(ofx_session *s, void *stream);
 /* Level k of the next frame's pyramid from level k-1, own rows only. */
 int ofx_session_downsample_level(ofx_session *s, int level, void *stream);
-/* All levels coarse->fine against the previous frame's pyramid (main.cu:256-262): for each level
- * ofx_session_compute_uv, then ofx_session_run_level. */
+/* All levels against the previous frame's pyramid (main.cu:256-262) in three launches: ofx_session_corner_flows,
+ * then ofx_session_run_levels (one multi-level shift launch, one multi-level LK launch). */
 int ofx_session_run_flow(ofx_session *s, void *stream);
+int ofx_session_corner_flows(ofx_session *s, void *stream);
+int ofx_session_run_levels(ofx_session *s, void *stream);
+/* The same result the reference's way: per level ofx_session_compute_uv then ofx_session_run_level, coarse to fine. */
+int ofx_session_run_flow_sequential(ofx_session *s, void *stream);
 /* Shift vector of `level` from the coarser flows' pixel 0 into the session's uv slot (meaningful on the rank that
  * owns row 0; a sharded driver broadcasts the slot before ofx_session_run_level). */
 int ofx_session_compute_uv(ofx_session *s, int level, void *stream);
@@ -204,7 +236,7 @@ int ofx_session_shift_uv(ofx_session *s, int level, float **d_uv);
 /* Copy one level's flow (the rows this session owns, tightly packed) to host, synchronising `stream`. */
 int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst, void *stream);
 
-/* Time the level-0 fused LK launch with HIP events recorded on the launch stream: arm for up to max_launches
+/* Time the fused LK launch (all levels in ofx_session_run_levels, level 0 in ofx_session_run_level) with HIP events recorded on the launch stream: arm for up to max_launches
  * launches (0 disarms); read returns the average/minimum duration in microseconds and re-arms. */
 int ofx_session_timing(ofx_session *s, int max_launches);
 int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int *launches);

@@ -193,6 +193,35 @@ def test_session_planes_and_streaming(eng, oracle):
     s.close()
 
 
+@pytest.mark.parametrize("mode", ["compat_cpu", "lk_float"])
+def test_corner_kernel_path_equals_sequential_path(eng, mode):
+    """run_flow = corner kernel + one multi-level shift launch + one multi-level LK launch; it must reproduce the
+    level-by-level sequence of main.cu:256-262 bit for bit (flows AND shift vectors)."""
+    import torch
+
+    for (w, h, L, win, gen) in ((320, 240, 4, 9, "smooth"), (256, 192, 3, 5, "random"), (64, 48, 3, 19, "smooth"), (16, 8, 2, 3, "random")):
+        p, n = synth.smooth_pair(w, h) if gen == "smooth" else synth.random_pair(w, h, seed=11)
+        s = eng.Session(w, h, L, win, mode)
+        s.push_frame_host(p)
+        s.set_frame_host(n)
+        s.build_pyramid()
+        s.run_flow_sequential()
+        torch.cuda.synchronize()
+        seq = [s.flow_host(k) for k in range(L)]
+        uv_seq = [s.uv(k).cpu().numpy().copy() for k in range(L - 1)]
+        for k in range(L):
+            s.flow(k)[0].zero_()
+        for k in range(L - 1):
+            s.uv(k).zero_()
+        s.run_flow()
+        torch.cuda.synchronize()
+        for k in range(L):
+            assert_same(s.flow_host(k), seq[k], f"{w}x{h} {mode} L{k}")
+        for k in range(L - 1):
+            assert_same(s.uv(k).cpu().numpy(), uv_seq[k], f"{w}x{h} {mode} uv L{k}")
+        s.close()
+
+
 def test_session_rejects_bad_configs(eng):
     from cuda_optical_flow_2_amd.lib import OfxError
 

@@ -26,6 +26,7 @@ for nm in names:
         s.set_frame_device(tn); s.build_pyramid(); s.run_flow()
     t = timeit(pair)
     print(f"{nm}: pair {t:.1f} us  {w*h/t:.0f} Mpix/s", end=" | ")
+    print(f"pyr {timeit(lambda: s.build_pyramid()):.1f} corner {timeit(lambda: s.corner_flows()):.1f} levels {timeit(lambda: s.run_levels()):.1f}", end=" | ")
     for k in range(L):
         tk = timeit(lambda: s.run_level(k))
         print(f"L{k} {tk:.1f}", end=" ")
@@ -33,5 +34,11 @@ for nm in names:
     for i in range(64): s.run_level(0)
     torch.cuda.synchronize()
     avg, mn, cnt = s.timing_read()
-    print(f"| L0 lk kernel avg {avg:.1f} min {mn:.1f} us -> {w*h*10/avg/1e3:.0f} GB/s ({w*h*10/avg/1e3/80:.1f}% of 8 TB/s)")
+    print(f"| L0 lk kernel avg {avg:.1f} min {mn:.1f} us -> {w*h*10/avg/1e3:.0f} GB/s ({w*h*10/avg/1e3/80:.1f}% of 8 TB/s)", end=" ")
+    s.timing(64)
+    for i in range(64): s.run_levels()
+    torch.cuda.synchronize()
+    avg, mn, cnt = s.timing_read()
+    tot = sum((w >> k) * (h >> k) for k in range(L))
+    print(f"| all-level lk launch avg {avg:.1f} min {mn:.1f} us -> {tot*10/avg/1e3:.0f} GB/s ({tot*10/avg/1e3/80:.1f}%)")
     s.close()
