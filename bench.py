@@ -136,8 +136,11 @@ def main():
 
     if rank == 0:
         ms = dt / args.steps * 1e3
-        own_rows = h if driver is None else (driver.plan.own[0][1] - driver.plan.own[0][0])
-        lk_bytes = LK_BYTES_PER_PX * w * own_rows
+        # the timed launch is the fused LK kernel over ALL pyramid levels (one launch, ofx_lk_levels): algorithmic
+        # bytes = 10 B x the pixels of every level this rank owns
+        own_px = sum((w >> k) * ((h >> k) if driver is None else (driver.plan.own[k][1] - driver.plan.own[k][0]))
+                     for k in range(levels))
+        lk_bytes = LK_BYTES_PER_PX * own_px
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -164,7 +167,7 @@ def main():
                 "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lk_level_kernel (level 0, fused derivatives + window sums + solve)",
+                "bound": "hbm", "kernel": "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),

@@ -21,6 +21,7 @@ struct ofx_session {
     int w[OFX_MAX_LEVELS]{}, h[OFX_MAX_LEVELS]{}, pitch[OFX_MAX_LEVELS]{};
     int own0[OFX_MAX_LEVELS]{}, own1[OFX_MAX_LEVELS]{}; // rows this rank computes
     int buf0[OFX_MAX_LEVELS]{}, buf1[OFX_MAX_LEVELS]{}; // rows the plane buffers hold
+    int cmp0[OFX_MAX_LEVELS]{}, cmp1[OFX_MAX_LEVELS]{}; // rows this rank downsamples itself
     uint8_t *plane[3][OFX_MAX_LEVELS]{};                // 0 prev, 1 next, 2 shifted scratch
     float *flow[OFX_MAX_LEVELS]{};
     float *uv = nullptr;        // 2 floats per level
@@ -77,8 +78,13 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own1[k] = p->own_y1[k];
             s->buf0[k] = p->buf_y0[k];
             s->buf1[k] = p->buf_y1[k];
+            const bool has_comp = p->comp_y1[k] > 0;
+            s->cmp0[k] = has_comp ? p->comp_y0[k] : s->own0[k];
+            s->cmp1[k] = has_comp ? p->comp_y1[k] : s->own1[k];
             const bool ok = 0 <= s->buf0[k] && s->buf0[k] <= s->own0[k] && s->own0[k] <= s->own1[k] &&
-                            s->own1[k] <= s->buf1[k] && s->buf1[k] <= s->h[k] && s->buf0[k] < s->buf1[k];
+                            s->own1[k] <= s->buf1[k] && s->buf1[k] <= s->h[k] && s->buf0[k] < s->buf1[k] &&
+                            s->buf0[k] <= s->cmp0[k] && s->cmp0[k] <= s->own0[k] && s->own1[k] <= s->cmp1[k] &&
+                            s->cmp1[k] <= s->buf1[k];
             if (!ok) {
                 ofx_set_error("ofx_session_create: level %d shard rows own [%d,%d) buf [%d,%d) invalid for height %d", k,
                               s->own0[k], s->own1[k], s->buf0[k], s->buf1[k], s->h[k]);
@@ -86,8 +92,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
                 return OFX_E_INVALID;
             }
         } else {
-            s->own0[k] = s->buf0[k] = 0;
-            s->own1[k] = s->buf1[k] = s->h[k];
+            s->own0[k] = s->buf0[k] = s->cmp0[k] = 0;
+            s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
         for (int t = 0; t < 3; ++t) {
@@ -185,7 +191,7 @@ extern "C" int ofx_session_downsample_level(ofx_session *s, int k, void *stream)
     OFX_REQUIRE(s, "ofx_session_downsample_level: null session");
     OFX_REQUIRE(k >= 1 && k < s->p.levels, "ofx_session_downsample_level: level %d out of range", k);
     OFX_REQUIRE(s->have_next, "ofx_session_downsample_level: no frame loaded");
-    const ofx_geom g = level_geom(s, k, s->own0[k], s->own1[k]);
+    const ofx_geom g = level_geom(s, k, s->cmp0[k], s->cmp1[k]);
     return ofx_downsample_1ch(s->plane[1][k - 1], s->pitch[k - 1], s->buf0[k - 1], s->buf1[k - 1] - s->buf0[k - 1],
                               s->plane[1][k], &g, stream);
 }

@@ -56,6 +56,7 @@ class Session:
             for k in range(levels):
                 p.own_y0[k], p.own_y1[k] = shard.own[k]
                 p.buf_y0[k], p.buf_y1[k] = shard.buf[k]
+                p.comp_y0[k], p.comp_y1[k] = shard.comp[k]
         self._h = _vp()
         check(self.L.ofx_session_create(C.byref(p), C.byref(self._h)), "ofx_session_create")
         self._keep = []

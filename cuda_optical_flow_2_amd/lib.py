@@ -35,6 +35,7 @@ class Params(C.Structure):
                 ("device", C.c_int), ("sharded", C.c_int),
                 ("own_y0", C.c_int * OFX_MAX_LEVELS), ("own_y1", C.c_int * OFX_MAX_LEVELS),
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
+                ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
                 ("reserved", C.c_int * 8)]
 
 

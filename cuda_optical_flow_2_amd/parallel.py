@@ -1,0 +1,184 @@
+"""Row-sharded dense LK over the GPUs of one node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).
+
+Partition.  The COARSEST pyramid level's rows are split as evenly as possible over the ranks and the cut is scaled up
+by 2 per level, so every level is cut at the same image position and a rank owns one contiguous row block per level.
+
+What crosses ranks.  Every stage is a finite-support stencil, so a rank only ever needs rows within a fixed distance
+of its block:
+  * LK at level k reads (radius + 1) rows beyond the block, the shift up to `margin` rows further;
+  * level k+1's rows are a 3-row stencil of level k (rows 2y-1 .. 2y+1).
+In the default "recompute" mode those halo rows are not fetched from the neighbours at every level: the rank takes a
+wider halo of the NEW FRAME's level 0 once (the frame arrives in every rank's HBM anyway) and rebuilds the halo rows of
+the coarser levels itself -- a few per cent more downsampling work instead of a latency-bound exchange per level.  The
+one true dependency between ranks is the reference's shift vector, which is formed from PIXEL 0 of every coarser flow
+level (OptFlowCPU.cpp:255-266): rank 0 owns that corner, runs the corner kernel, and broadcasts the 2*levels floats --
+one small collective per frame pair.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+Range = Tuple[int, int]
+
+
+def _clip(lo: int, hi: int, n: int) -> Range:
+    return max(0, lo), min(n, hi)
+
+
+@dataclass
+class ShardPlan:
+    """Row ranges of one rank at every pyramid level (all global row indices, half-open)."""
+
+    width: int
+    height: int
+    levels: int
+    window: int
+    rank: int
+    world: int
+    margin: int = 8  # rows of slack for the reference's global shift (|v| <= margin keeps the shift exact)
+    own: List[Range] = field(default_factory=list)   # rows whose flow this rank computes
+    need: List[Range] = field(default_factory=list)  # rows of the images LK + shift may touch
+    comp: List[Range] = field(default_factory=list)  # rows this rank downsamples itself (levels >= 1)
+    buf: List[Range] = field(default_factory=list)   # rows its plane buffers hold
+
+    def __post_init__(self):
+        L = self.levels
+        hs = [self.height >> k for k in range(L)]
+        for k in range(L - 1):
+            if hs[k] % 2 or (self.width >> k) % 2:
+                raise ValueError(f"level {k} ({self.width >> k}x{hs[k]}) must have even dimensions to be downsampled")
+        hc = hs[L - 1]
+        if hc < self.world:
+            raise ValueError(f"cannot split {hc} coarsest-level rows over {self.world} ranks")
+        base, extra = divmod(hc, self.world)
+        c0 = self.rank * base + min(self.rank, extra)
+        c1 = c0 + base + (1 if self.rank < extra else 0)
+        halo = self.window // 2 + 1 + self.margin
+        self.own = [(c0 << (L - 1 - k), c1 << (L - 1 - k)) for k in range(L)]
+        self.need = [_clip(self.own[k][0] - halo, self.own[k][1] + halo, hs[k]) for k in range(L)]
+        # recompute mode: walk down from the coarsest level; what level k+1 computes dictates what level k must hold
+        self.comp = [None] * L
+        self.buf = [None] * L
+        self.comp[L - 1] = self.need[L - 1]
+        self.buf[L - 1] = self.need[L - 1]
+        for k in range(L - 2, -1, -1):
+            src = _clip(2 * self.comp[k + 1][0] - 1, 2 * self.comp[k + 1][1] + 1, hs[k])  # rows 2y-1 .. 2y+1
+            lo, hi = min(self.need[k][0], src[0]), max(self.need[k][1], src[1])
+            self.buf[k] = (lo, hi)
+            self.comp[k] = (lo, hi)
+        if L == 1:
+            self.comp[0] = self.buf[0] = self.need[0]
+
+    def redundancy(self) -> float:
+        """Fraction of extra level-0 rows held beyond the owned block (the price of exchanging nothing per level)."""
+        own = self.own[0][1] - self.own[0][0]
+        return (self.buf[0][1] - self.buf[0][0]) / max(1, own) - 1.0
+
+
+class HipBackend:
+    """The device-resident session of libofx_hip.so behind the operations ShardedFlow needs."""
+
+    def __init__(self, plan: ShardPlan, mode: str, device: int):
+        from . import engine
+
+        self.plan = plan
+        self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan)
+        # the session keeps 2 floats per level contiguously; a view over all of them is what gets broadcast
+        self.uv_all = engine.DeviceView(self.session.uv(0).data_ptr(), (2 * plan.levels,), "<f4").tensor()
+        # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
+        self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
+
+    def load_frame(self, frame):
+        self.session.set_frame_device(frame)
+
+    def build_pyramid(self):
+        self.session.build_pyramid()
+
+    def corner_flows(self):
+        self.session.corner_flows()
+
+    def run_levels(self):
+        self.session.run_levels()
+
+    def swap(self):
+        self.session.swap()
+
+    def flow(self, level: int):
+        return self.session.flow(level)[0]
+
+
+class ShardedFlow:
+    """One frame pair per step(), row-sharded over the ranks of the default process group."""
+
+    def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None):
+        self.plan = ShardPlan(width, height, levels, window, rank, world, margin)
+        self.rank, self.world = rank, world
+        self.backend = backend if backend is not None else HipBackend(self.plan, mode, device)
+        self.session = getattr(self.backend, "session", None)
+
+    def push_frame(self, frame):
+        """Make `frame` the previous frame (priming, main.cu:203-209)."""
+        b = self.backend
+        b.load_frame(frame)
+        b.build_pyramid()
+        b.swap()
+
+    def step(self, frame, check_margin: bool = False):
+        """Flow between the previous frame and `frame`; afterwards `frame` is the previous frame."""
+        import torch.distributed as dist
+
+        b = self.backend
+        b.load_frame(frame)
+        b.build_pyramid()
+        if self.rank == 0:
+            b.corner_flows()  # needs only rank 0's own corner of every level
+        if self.world > 1:
+            stage = getattr(b, "uv_stage", None)
+            if stage is None:
+                dist.broadcast(b.uv_all, src=0)
+            else:
+                if self.rank == 0:
+                    stage.copy_(b.uv_all)
+                dist.broadcast(stage, src=0)
+                b.uv_all.copy_(stage)
+        if check_margin:
+            self.assert_margin()
+        b.run_levels()
+        b.swap()
+
+    def assert_margin(self):
+        """The shift is exact while every level's vertical shift stays within the halo margin (host sync: tests only)."""
+        import math
+
+        uv = self.backend.uv_all.detach().cpu().tolist()
+        halo = self.plan.window // 2 + 1
+        for k in range(self.plan.levels - 1):
+            v, hk = uv[2 * k + 1], self.plan.height >> k
+            if not math.isfinite(v) or abs(v) <= self.plan.margin:
+                continue  # non-finite: every target is outside the image, nothing is fetched (OptFlowCPU.cpp:270)
+            y0 = max(0, self.plan.own[k][0] - halo)
+            y1 = min(hk, self.plan.own[k][1] + halo)
+            lo, hi = y0 + v, (y1 - 1) + v  # targets of the rows this rank shifts
+            if hi > -1 and lo < hk:        # some target lands inside the image: its row must be in the buffer
+                raise RuntimeError(f"level {k}: vertical shift {v:.2f} exceeds the halo margin {self.plan.margin}; "
+                                   "re-create the plan with a larger margin")
+
+    def gather_flow(self, level: int):
+        """Full (h_k, w_k, 2) flow of a level on every rank (tests / host consumers)."""
+        import torch
+        import torch.distributed as dist
+
+        mine = self.backend.flow(level).contiguous()
+        if self.world == 1:
+            return mine
+        w = self.plan.width >> level
+        rows = [ShardPlan(self.plan.width, self.plan.height, self.plan.levels, self.plan.window, r, self.world,
+                          self.plan.margin).own[level] for r in range(self.world)]
+        most = max(b - a for a, b in rows)
+        padded = torch.zeros((most, w, 2), dtype=mine.dtype, device=mine.device)  # equal-sized pieces for all_gather
+        padded[: mine.shape[0]] = mine
+        parts = [torch.empty_like(padded) for _ in rows]
+        dist.all_gather(parts, padded)
+        return torch.cat([p[: b - a] for p, (a, b) in zip(parts, rows)], dim=0)

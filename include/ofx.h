@@ -198,10 +198,14 @@ typedef struct ofx_params {
     /* Row sharding.  sharded == 0: this session holds whole levels.  sharded != 0: for level k this
      * rank OWNS global rows [own_y0[k], own_y1[k]) -- it computes the pyramid and the flow for them -- and its
      * plane buffers HOLD rows [buf_y0[k], buf_y1[k]) (own rows plus halo; the halo rows are filled by the
-     * caller's exchange between ofx_session_downsample_level and ofx_session_run_level). */
+     * caller's exchange between ofx_session_downsample_level and ofx_session_run_levels, or recomputed: comp_y*). */
     int sharded;
     int own_y0[OFX_MAX_LEVELS], own_y1[OFX_MAX_LEVELS];
     int buf_y0[OFX_MAX_LEVELS], buf_y1[OFX_MAX_LEVELS];
+    /* rows of level k (k >= 1) this rank produces itself when it builds the pyramid, own <= comp <= buf.
+     * comp == own: halos come from the neighbours (exchange); comp == buf: halos are recomputed locally from a
+     * wider halo one level below (no exchange).  Ignored (treated as own) when comp_y1[k] == 0. */
+    int comp_y0[OFX_MAX_LEVELS], comp_y1[OFX_MAX_LEVELS];
     int reserved[8];
 } ofx_params;
 

@@ -222,6 +222,46 @@ def test_corner_kernel_path_equals_sequential_path(eng, mode):
         s.close()
 
 
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_sharded_sessions_on_one_device(eng, mode):
+    """SURVEY 8e verification step: R logical ranks (sharded HIP sessions built from parallel.ShardPlan) on one device
+    reproduce the unsharded result bit for bit.  Rank 0's shift vectors are handed to the others with a device copy --
+    the place the RCCL broadcast takes in a real multi-GPU run (tests/test_parallel.py covers that under gloo)."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import HipBackend, ShardPlan
+
+    w, h, L, win, R = 640, 480, 4, 9, 4
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.5 * i, 0.75 * i, seed=3)[1]).cuda() for i in range(3)]
+    whole = eng.Session(w, h, L, win, mode)
+    ranks = [HipBackend(ShardPlan(w, h, L, win, r, R), mode, 0) for r in range(R)]
+    for b in [whole] + [r.session for r in ranks]:
+        b.set_frame_device(frames[0])
+        b.build_pyramid()
+        b.swap()
+    for i in (1, 2):
+        whole.set_frame_device(frames[i])
+        whole.build_pyramid()
+        whole.run_flow()
+        for r in ranks:
+            r.load_frame(frames[i])
+            r.build_pyramid()
+        ranks[0].corner_flows()
+        for r in ranks[1:]:
+            r.uv_all.copy_(ranks[0].uv_all)
+        for r in ranks:
+            r.run_levels()
+        torch.cuda.synchronize()
+        for k in range(L):
+            got = torch.cat([r.flow(k) for r in ranks], dim=0).cpu().numpy()
+            assert_same(got, whole.flow_host(k), f"{mode} frame {i} level {k}")
+        whole.swap()
+        for r in ranks:
+            r.swap()
+    whole.close()
+    for r in ranks:
+        r.session.close()
+
+
 def test_session_rejects_bad_configs(eng):
     from cuda_optical_flow_2_amd.lib import OfxError
 

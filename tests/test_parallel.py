@@ -1,0 +1,194 @@
+"""CPU: the row-sharding plan and the N > 1 driver (cuda_optical_flow_2_amd/parallel.py) under gloo, world_size 2 and 3.
+
+The per-rank compute here is an ORACLE-backed stand-in for the HIP session (same interface, numpy + oracle calls), so
+the test exercises exactly what multi-GPU adds: the partition, the halo/recompute ranges, the broadcast of the shift
+vectors and the reassembly -- and checks the sharded result against the unsharded oracle bit for bit.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cuda_optical_flow_2_amd import synth
+from cuda_optical_flow_2_amd.parallel import ShardPlan, ShardedFlow
+
+
+# ---- plan invariants -------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("cfg", [(3840, 2160, 5, 9, 8), (1920, 1080, 4, 7, 4), (7680, 4320, 6, 15, 8), (640, 480, 3, 5, 2),
+                                 (256, 192, 3, 9, 3), (64, 48, 1, 5, 2)])
+def test_plan_invariants(cfg):
+    w, h, L, win, world = cfg
+    plans = [ShardPlan(w, h, L, win, r, world) for r in range(world)]
+    for k in range(L):
+        hk = h >> k
+        cuts = [p.own[k] for p in plans]
+        assert cuts[0][0] == 0 and cuts[-1][1] == hk
+        assert all(a[1] == b[0] for a, b in zip(cuts[:-1], cuts[1:])), "own blocks must tile the level"
+        for p in plans:
+            o, n, c, b = p.own[k], p.need[k], p.comp[k], p.buf[k]
+            assert b[0] <= n[0] <= o[0] <= o[1] <= n[1] <= b[1] and 0 <= b[0] < b[1] <= hk
+            assert b[0] <= c[0] <= o[0] and o[1] <= c[1] <= b[1]
+            halo = win // 2 + 1 + p.margin
+            assert n[0] == max(0, o[0] - halo) and n[1] == min(hk, o[1] + halo)
+            if k + 1 < L:  # everything level k+1 computes is a 3-row stencil of rows this rank holds at level k
+                c1 = p.comp[k + 1]
+                assert b[0] <= max(0, 2 * c1[0] - 1) and min(hk, 2 * c1[1] + 1) <= b[1]
+    if cfg[0] == 3840:
+        # 4K over 8 ranks: 135 coarse rows -> 17 x 7 + 16, level-0 blocks of 272 / 256 rows
+        assert [p.own[4][1] - p.own[4][0] for p in plans] == [17] * 7 + [16]
+        assert [p.own[0][1] - p.own[0][0] for p in plans] == [272] * 7 + [256]
+
+
+def test_plan_rejects_impossible_splits():
+    with pytest.raises(ValueError):
+        ShardPlan(64, 48, 4, 5, 0, 8)       # 6 coarse rows over 8 ranks
+    with pytest.raises(ValueError):
+        ShardPlan(100, 50, 3, 5, 0, 2)      # odd level gets downsampled
+
+
+# ---- oracle-backed rank ---------------------------------------------------------------------------------------------
+
+class OracleBackend:
+    """numpy/oracle stand-in for HipBackend: one rank's buffers hold only the rows plan.buf says they hold."""
+
+    def __init__(self, plan, mode):
+        import torch
+        from oracle import Oracle
+
+        self.plan, self.mode, self.orc = plan, mode, Oracle()
+        L = plan.levels
+        self.w = [plan.width >> k for k in range(L)]
+        self.h = [plan.height >> k for k in range(L)]
+        self.prev, self.next = [None] * L, [None] * L
+        self.flows = [np.zeros((plan.own[k][1] - plan.own[k][0], self.w[k], 2), np.float32) for k in range(L)]
+        self.uv_all = torch.zeros(2 * L, dtype=torch.float32)
+
+    def load_frame(self, frame):
+        b0, b1 = self.plan.buf[0]
+        self.next[0] = np.asarray(frame)[b0:b1].copy()
+
+    def build_pyramid(self):
+        p = self.plan
+        for k in range(1, p.levels):
+            c0, c1 = p.comp[k]
+            assert (c0, c1) == p.buf[k]
+            s0, s1 = max(0, 2 * c0 - 2), 2 * c1              # even-aligned source crop; its first row may be unused
+            src0 = p.buf[k - 1][0]
+            crop = np.zeros((s1 - s0, self.w[k - 1]), np.uint8)
+            lo = max(s0, src0)
+            assert s1 <= p.buf[k - 1][1] and lo <= max(0, 2 * c0 - 1), "plan does not hold the rows the stencil needs"
+            crop[lo - s0:] = self.next[k - 1][lo - src0: s1 - src0]
+            out = self.orc.downscale_gaussian(synth.to_3ch(crop))[:, :, 0]
+            self.next[k] = out[c0 - s0 // 2:].copy()
+            assert self.next[k].shape[0] == c1 - c0
+
+    def _shift_rows(self, k, u, v, y0, y1):
+        """cpu::shift_back_pyramid on channel 0 for global rows [y0,y1) of level k, from this rank's buffer only."""
+        w, h, b0 = self.w[k], self.h[k], self.plan.buf[k][0]
+        src = self.next[k]
+        u, v = np.float32(u), np.float32(v)
+        out = np.zeros((y1 - y0, w), np.uint8)
+        xs = np.arange(w)
+        tx = xs.astype(np.float32) + u
+        xin = (tx > -1) & (tx < w)
+        nx = np.where(xin, np.trunc(np.where(xin, tx, 0)), 0).astype(np.int64)
+        for y in range(y0, y1):
+            ty = np.float32(y) + v
+            keep = 3 * (y * w + xs) < w * h
+            fallback = np.where(keep, src[y - b0], 0)
+            if ty > -1 and ty < h:
+                ny = int(np.trunc(ty))
+                assert b0 <= ny < b0 + src.shape[0], "shift target outside the halo margin"
+                out[y - y0] = np.where(xin, src[ny - b0, nx], fallback)
+            else:
+                out[y - y0] = fallback
+        return out
+
+    def _level(self, prev_crop, next_crop):
+        fl = [np.zeros(prev_crop.shape + (2,), np.float32)]
+        p3, n3 = synth.to_3ch(prev_crop), synth.to_3ch(next_crop)
+        if self.mode == "compat_cpu":
+            self.orc.calc_optical_flow_cpu(p3, n3, fl, 0, 1, self.plan.window)
+        else:
+            self.orc.calc_opt_flow_gpu(p3, n3, fl, 0, 1, self.plan.window, exact_sums=True)
+        return fl[0]
+
+    def corner_flows(self):
+        p, L, r = self.plan, self.plan.levels, self.plan.window // 2
+        assert p.rank == 0
+        f0 = {}
+        for k in range(L - 1, -1, -1):
+            u = v = np.float32(0)
+            for j in range(L - 1, k, -1):
+                m = np.float32(1 << (j - k))
+                u = np.float32(u + m * f0[j][0])
+                v = np.float32(v + m * f0[j][1])
+            rows, cols = min(self.h[k], r + 2), min(self.w[k], r + 2)
+            if k != L - 1:
+                self.uv_all[2 * k], self.uv_all[2 * k + 1] = float(u), float(v)
+                nxt = self._shift_rows(k, u, v, 0, rows)
+            else:
+                nxt = self.next[k][:rows]
+            f0[k] = self._level(self.prev[k][:rows, :cols], nxt[:, :cols])[0, 0]
+
+    def run_levels(self):
+        p, L, halo = self.plan, self.plan.levels, self.plan.window // 2 + 1
+        for k in range(L):
+            o0, o1 = p.own[k]
+            y0, y1 = max(0, o0 - halo), min(self.h[k], o1 + halo)
+            b0 = p.buf[k][0]
+            if k != L - 1:
+                nxt = self._shift_rows(k, float(self.uv_all[2 * k]), float(self.uv_all[2 * k + 1]), y0, y1)
+            else:
+                nxt = self.next[k][y0 - b0: y1 - b0]
+            self.flows[k] = self._level(self.prev[k][y0 - b0: y1 - b0], nxt)[o0 - y0: o1 - y0].copy()
+
+    def swap(self):
+        self.prev, self.next = self.next, [None] * self.plan.levels
+
+    def flow(self, level):
+        import torch
+
+        return torch.from_numpy(self.flows[level])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, cfg, mode):
+    import torch.distributed as dist
+    from conftest import assert_same
+    from oracle import Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h, L, win, margin = cfg
+        frames = [synth.smooth_pair(w, h, 1.5 * i, 0.75 * i, seed=5)[1] for i in range(3)]
+        plan = ShardPlan(w, h, L, win, rank, world, margin)
+        sf = ShardedFlow(w, h, L, win, mode, rank, world, margin=margin, backend=OracleBackend(plan, mode))
+        sf.push_frame(frames[0])
+        orc = Oracle()
+        for i in (1, 2):
+            sf.step(frames[i], check_margin=True)
+            want, _, _ = orc.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), L, win, mode, exact_sums=True)
+            for k in range(L):
+                got = sf.gather_flow(k).numpy()
+                assert_same(got, want[k], f"rank {rank}/{world} frame {i} level {k}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_sharded_flow_gloo(world, mode):
+    import torch.multiprocessing as mp
+
+    cfg = (96, 144, 3, 5, 8)  # 36 coarse rows; window 5; halo margin 8
+    mp.spawn(_rank_main, args=(world, _free_port(), cfg, mode), nprocs=world, join=True)
