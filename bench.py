@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
+    ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
+                    help="single-GPU execution path: stream pipeline (default), two-stream staged pairs, or the plain sequence")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -94,11 +96,26 @@ def main():
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank)
         sess.push_frame_host(frames[0])
 
-        def step(i):
-            sess.set_frame_device(d_frames[(i + 1) % nframes])
-            sess.build_pyramid()
-            sess.run_flow()
-            sess.swap()
+        if args.path == "stream":
+            # one launch per frame: pyramid(frame j) | corner(pair j-1) | shifts(pair j-2) | LK(pair j-3) side by side in
+            # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
+            sess.stream_begin()
+            for i in range(3):
+                sess.stream_submit(d_frames[i % nframes])
+
+            def step(i):
+                sess.stream_submit(d_frames[i % nframes])
+        elif args.path == "staged":
+            # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
+            # pair's LK launch
+            def step(i):
+                sess.submit_device(d_frames[(i + 1) % nframes])
+        else:
+            def step(i):
+                sess.set_frame_device(d_frames[(i + 1) % nframes])
+                sess.build_pyramid()
+                sess.run_flow()
+                sess.swap()
 
         driver = None
     else:
@@ -167,7 +184,9 @@ def main():
                 "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)",
+                "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels + pyramid + corner + shifts; bytes counted: LK only)"
+                           if world == 1 and args.path == "stream" else
+                           "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),

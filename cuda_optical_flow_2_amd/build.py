@@ -15,8 +15,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
-OUT = os.path.join(PKG, "libofx_hip.so")
-OBJ = os.path.join(PKG, "csrc", "_obj")
+OUT = os.path.join(PKG, os.environ.get("OFX_BUILD_OUT", "libofx_hip.so"))  # experiments: alternative builds side by side
+OBJ = os.path.join(PKG, "csrc", "_obj" + os.environ.get("OFX_BUILD_TAG", ""))
 ARCH = "gfx950"
 
 SOURCES = ["lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp", "compat_gpu.cpp"]
@@ -24,7 +24,7 @@ SOURCES = ["lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_c
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
 # buys nothing on gfx950 (packed fp32 issues at half the rate of scalar fp32; tools/ubench/valu_rates.hip)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize", f"--offload-arch={ARCH}", "-I" + INCLUDE, "-I" + CSRC,
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("OFX_BUILD_DEFS", "").split()
 
 
 def hipcc() -> str:

@@ -22,431 +22,57 @@
 // (OptFlowCPU.cpp:182-191) -- i.e. the image and the derivative planes are zero-extended.
 #include <stdlib.h>
 
-#include <type_traits>
+#include "corner_body.h"
+#include "lk_body.h"
+#include "stages_body.h"
 
-#include "lk_solve.h"
-#include "ofx_internal.h"
+using namespace ofx_dev;
 
 namespace {
 
-struct LkArgs {
-    const uint8_t *prev;
-    const uint8_t *next;
-    float *flow;   // interleaved (u,v), 2*w floats per row, row (y - flow_row0)
-    int32_t *sums; // optional: 5 planes of w ints per row (test/inspection variant)
-    size_t sums_plane;
-    int w, h, pitch, row0, row_end; // buffer holds global rows [row0,row_end)
-    int out_y0, out_y1, flow_row0;
-    int strip_h, tiles_x;
-};
-
-// one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
-struct LkTable {
-    LkArgs lv[OFX_MAX_LEVELS];
-    int first_block[OFX_MAX_LEVELS + 1];
-    int n;
-};
-
-// value of x held by lane (lane + D); 0 where that lane does not exist.  gfx9 DPP whole-wave shifts.
-// One whole-wave shift by a single lane.  The empty asm makes the moved value opaque so that hipcc's DPP combiner
-// cannot fold the move into its consumer: with ROCm 7.2 the folded form (v_subrev_u32_dpp) gave results shifted by
-// one lane in the compat_cpu derivative stage (found by the parity test; tools/dbg.py shows the impulse response).
-__device__ __forceinline__ int lane_shift_right(int x) // lane l receives lane l-1's value
-{
-    int r = __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
-    asm volatile("" : "+v"(r));
-    return r;
-}
-__device__ __forceinline__ int lane_shift_left(int x) // lane l receives lane l+1's value
-{
-    int r = __builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-    asm volatile("" : "+v"(r));
-    return r;
-}
-
-template <int D>
-__device__ __forceinline__ int lane_from(int x)
-{
-    if constexpr (D == 0) {
-        return x;
-    } else if constexpr (D > 0) {
-        return lane_from<D - 1>(lane_shift_left(x));
-    } else {
-        return lane_from<D + 1>(lane_shift_right(x));
-    }
-}
-
-// ---- horizontal box sum over columns [c-R, c+R] for the 4 columns of a lane -------------------------------
-// q[k] = a0+..+ak, s[k] = ak+..+a3 (q[3] == s[0] == lane total).
-template <int R, int I, int D>
-__device__ __forceinline__ int hbox_right(const int (&q)[4])
-{
-    constexpr int hi = I + R; // last relative column of the window; lane +D holds relative columns 4D..4D+3
-    if constexpr (hi < 4 * D) {
-        return 0;
-    } else if constexpr (hi >= 4 * D + 3) {
-        return lane_from<D>(q[3]) + hbox_right<R, I, D + 1>(q);
-    } else {
-        return lane_from<D>(q[hi - 4 * D]);
-    }
-}
-
-template <int R, int I, int D>
-__device__ __forceinline__ int hbox_left(const int (&s)[4])
-{
-    constexpr int lo = I - R; // first relative column; lane -D holds relative columns -4D..-4D+3
-    if constexpr (lo > -4 * D + 3) {
-        return 0;
-    } else if constexpr (lo <= -4 * D) {
-        return lane_from<-D>(s[0]) + hbox_left<R, I, D + 1>(s);
-    } else {
-        return lane_from<-D>(s[lo + 4 * D]);
-    }
-}
-
-template <int R, int I>
-__device__ __forceinline__ int hbox_one(const int (&q)[4], const int (&s)[4])
-{
-    constexpr int lo = I - R, hi = I + R;
-    constexpr int olo = lo > 0 ? lo : 0, ohi = hi < 3 ? hi : 3;
-    int own;
-    if constexpr (olo == 0) {
-        own = q[ohi];
-    } else if constexpr (ohi == 3) {
-        own = s[olo];
-    } else {
-        own = q[ohi] - q[olo - 1];
-    }
-    return own + hbox_right<R, I, 1>(q) + hbox_left<R, I, 1>(s);
-}
-
-template <int R>
-__device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
-{
-    int q[4], s[4];
-    q[0] = a[0];
-    q[1] = q[0] + a[1];
-    q[2] = q[1] + a[2];
-    q[3] = q[2] + a[3];
-    s[3] = a[3];
-    s[2] = s[3] + a[2];
-    s[1] = s[2] + a[1];
-    s[0] = q[3];
-    out[0] = hbox_one<R, 0>(q, s);
-    out[1] = hbox_one<R, 1>(q, s);
-    out[2] = hbox_one<R, 2>(q, s);
-    out[3] = hbox_one<R, 3>(q, s);
-}
-
-// geometry of a wave tile for radius R (also used by the host)
-template <int R>
-struct TileGeom {
-    static constexpr int LO_LANE = (R + 1 + 3) / 4; // first lane whose 4 outputs have all their taps inside the wave
-    static constexpr int HI_LANE = (251 - R) / 4;   // last such lane (derivatives are valid for wave columns 1..254)
-    static constexpr int OUT_W = (HI_LANE - LO_LANE + 1) * 4;
-};
-
-// ---- rows ---------------------------------------------------------------------------------------------------------
-// MI355X VALU cost model (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt): v_add_u32 / v_and / fp32 add,
-// mul, fma issue in ~2 cycles per wave; integer multiply, bfe, DPP, SDWA, packed-16 and every fp64 op take ~4.
-// So the arithmetic below is done in fp32 on values that are small exact integers (|Ix|,|Iy| <= 1020,
-// |It| <= 3825, products < 2^22), and only the running sums are 32-bit integers.
-template <int MODE>
-struct Row; // one image row of this lane's 4 columns, unpacked
-template <>
-struct Row<OFX_MODE_LK_FLOAT> {
-    float p[4]; // prev
-    float d[4]; // next - prev   (It is linear: Dt (*) next - Dt (*) prev == Dt (*) (next - prev), OptFlowGpu.cu:1936-1940)
-};
-template <>
-struct Row<OFX_MODE_COMPAT_CPU> {
-    int p[4]; // prev
-    int n[4]; // next
-};
-
-__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_LK_FLOAT> &r)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.p[j] = (float)((praw >> (8 * j)) & 0xffu); // v_cvt_f32_ubyteN
-        r.d[j] = (float)((nraw >> (8 * j)) & 0xffu) - r.p[j];
-    }
-}
-
-__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_COMPAT_CPU> &r)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.p[j] = (praw >> (8 * j)) & 0xff;
-        r.n[j] = (nraw >> (8 * j)) & 0xff;
-    }
-}
-
-__device__ __forceinline__ float lane_from_f(float x, bool left)
-{
-    const int xi = __float_as_int(x);
-    return __int_as_float(left ? lane_from<-1>(xi) : lane_from<1>(xi));
-}
-
-__device__ __forceinline__ float fmask(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
-
-// Derivatives of the middle row of a 3-row window at this lane's 4 columns, as exact small integers held in floats.
-// cm[j] = all-ones when column j is inside the image.  Only Ix and Iy are masked: every product the window sums use
-// has Ix or Iy as a factor, so a zero (Ix,Iy) pair removes the pixel whatever It is.
-__device__ __forceinline__ void derivs(const Row<OFX_MODE_LK_FLOAT> &t, const Row<OFX_MODE_LK_FLOAT> &m,
-                                       const Row<OFX_MODE_LK_FLOAT> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
-                                       float (&it)[4])
-{
-    // separable Sobel pair (kernels.cpp:6-19): sm = [1 2 1]^T column sums, df = [-1 0 1]^T column differences;
-    // Dt_3x3 = [1 2 1]^T [1 2 1] - centre tap (kernels.cpp:20-24) applied to d = next - prev
-    float sm[6], df[6], g[6];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sm[j + 1] = __builtin_fmaf(2.0f, m.p[j], t.p[j]) + b.p[j];
-        df[j + 1] = b.p[j] - t.p[j];
-        g[j + 1] = __builtin_fmaf(2.0f, m.d[j], t.d[j]) + b.d[j];
-    }
-    sm[0] = lane_from_f(sm[4], true);
-    sm[5] = lane_from_f(sm[1], false);
-    df[0] = lane_from_f(df[4], true);
-    df[5] = lane_from_f(df[1], false);
-    g[0] = lane_from_f(g[4], true);
-    g[5] = lane_from_f(g[1], false);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ix[j] = fmask(sm[j + 2] - sm[j], cm[j]);
-        iy[j] = fmask(__builtin_fmaf(2.0f, df[j + 1], df[j]) + df[j + 2], cm[j]);
-        it[j] = __builtin_fmaf(2.0f, g[j + 1], g[j]) + g[j + 2] - m.d[j];
-    }
-}
-
-__device__ __forceinline__ void derivs(const Row<OFX_MODE_COMPAT_CPU> &t, const Row<OFX_MODE_COMPAT_CPU> &m,
-                                       const Row<OFX_MODE_COMPAT_CPU> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
-                                       float (&it)[4])
-{
-    // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap contributes
-    // floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64).
-    // side[] = a column's contribution when it is left/right of the centre, mid[] when it is the centre column;
-    // bits 0..15 hold prev, bits 16..31 next (both halves stay < 256: no carry between them).
-    int sm[6], df[6], side[6], mid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sm[j + 1] = t.p[j] + 2 * m.p[j] + b.p[j];
-        df[j + 1] = b.p[j] - t.p[j];
-        const int sp = (t.p[j] >> 4) + (m.p[j] >> 3) + (b.p[j] >> 4);
-        const int sn = (t.n[j] >> 4) + (m.n[j] >> 3) + (b.n[j] >> 4);
-        const int mp = (t.p[j] >> 3) + (m.p[j] >> 2) + (b.p[j] >> 3);
-        const int mn = (t.n[j] >> 3) + (m.n[j] >> 2) + (b.n[j] >> 3);
-        side[j + 1] = sp | (sn << 16);
-        mid[j] = mp | (mn << 16);
-    }
-    sm[0] = lane_from<-1>(sm[4]);
-    sm[5] = lane_from<1>(sm[1]);
-    df[0] = lane_from<-1>(df[4]);
-    df[5] = lane_from<1>(df[1]);
-    side[0] = lane_from<-1>(side[4]);
-    side[5] = lane_from<1>(side[1]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m8 = cm[j] & 0xff; // (unsigned char) wrap, OptFlowCPU.cpp:106
-        const int gsum = side[j] + mid[j] + side[j + 2];
-        ix[j] = (float)((sm[j + 2] - sm[j]) & m8);
-        iy[j] = (float)((df[j] + 2 * df[j + 1] + df[j + 2]) & m8);
-        it[j] = (float)(((gsum >> 16) - (gsum & 0xffff)) & 0xff); // It2 - It1 as unsigned char, OptFlowCPU.cpp:15,340
-    }
-}
-
-// a*b as an exact int32 through the fp32 pipe: for integer-valued |a*b| < 2^22, fma(a, b, 1.5*2^23) has the product
-// in its low mantissa bits, so bits(fma) - bits(1.5*2^23) == a*b.  (fma f32: 2 cycles; v_mul_i32_i24: 4.)
-#define OFX_MAGIC 12582912.0f
-#define OFX_MAGIC_BITS 0x4B400000
-
-template <bool HAVE_OUT>
-__device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&iy)[4], const float (&it)[4],
-                                           const float (&ox)[4], const float (&oy)[4], const float (&ot)[4], int (&vxx)[4],
-                                           int (&vyy)[4], int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
-{
-    // order of the planes: OptFlowCPU.cpp:347-358 / OptFlowGpu.cu:1948-1960
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int axx = __float_as_int(__builtin_fmaf(ix[j], ix[j], OFX_MAGIC));
-        const int ayy = __float_as_int(__builtin_fmaf(iy[j], iy[j], OFX_MAGIC));
-        const int axy = __float_as_int(__builtin_fmaf(ix[j], iy[j], OFX_MAGIC));
-        const int axt = __float_as_int(__builtin_fmaf(ix[j], it[j], OFX_MAGIC));
-        const int ayt = __float_as_int(__builtin_fmaf(iy[j], it[j], OFX_MAGIC));
-        int sxx = OFX_MAGIC_BITS, syy = OFX_MAGIC_BITS, sxy = OFX_MAGIC_BITS, sxt = OFX_MAGIC_BITS, syt = OFX_MAGIC_BITS;
-        if constexpr (HAVE_OUT) {
-            sxx = __float_as_int(__builtin_fmaf(ox[j], ox[j], OFX_MAGIC));
-            syy = __float_as_int(__builtin_fmaf(oy[j], oy[j], OFX_MAGIC));
-            sxy = __float_as_int(__builtin_fmaf(ox[j], oy[j], OFX_MAGIC));
-            sxt = __float_as_int(__builtin_fmaf(ox[j], ot[j], OFX_MAGIC));
-            syt = __float_as_int(__builtin_fmaf(oy[j], ot[j], OFX_MAGIC));
-        }
-        vxx[j] += axx - sxx;
-        vyy[j] += ayy - syy;
-        vxy[j] += axy - sxy;
-        vxt[j] += axt - sxt;
-        vyt[j] += ayt - syt;
-    }
-}
-
-#ifndef OFX_LK_WAVES_PER_SIMD
-#define OFX_LK_WAVES_PER_SIMD 1
+#ifndef OFX_LK_MIN_WAVES
+#define OFX_LK_MIN_WAVES(R) 3 // A/B on MI355X: capping at 128 VGPRs (4 waves) spills in the marching loop and is slower
 #endif
 template <int R, int MODE, bool SUMS>
-__global__ __launch_bounds__(64, OFX_LK_WAVES_PER_SIMD) void lk_level_kernel(const LkTable T)
+__global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const LkTable T)
 {
-    using G = TileGeom<R>;
-    constexpr int NS = 2 * R + 1;
+    lk_wave<R, MODE, SUMS>(T, (int)blockIdx.x, (int)threadIdx.x);
+}
 
-    int level = 0;
-    while (level + 1 < T.n && (int)blockIdx.x >= T.first_block[level + 1]) ++level;
-    const LkArgs &A = T.lv[level];
-    const int block = (int)blockIdx.x - T.first_block[level];
-    const int lane = threadIdx.x;
-    const int tile = block % A.tiles_x;
-    const int strip = block / A.tiles_x;
-    const int cb = tile * G::OUT_W - G::LO_LANE * 4 + 4 * lane; // first of this lane's 4 image columns
-    const int ys = A.out_y0 + strip * A.strip_h;
-    const int ye = min(ys + A.strip_h, A.out_y1);
+// ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
+// Launch j of a frame stream runs, as disjoint block ranges of ONE grid,
+//     pyramid(frame j)  |  corner flows(pair j-1)  |  shifts(pair j-2)  |  fused LK(pair j-3)
+// Each stage consumes what launch j-1 wrote, so there is no synchronisation inside the launch and none between streams;
+// the small latency-bound stages run in the shadow of the VALU-bound LK stage.  Blocks are 256 threads; an LK block is
+// four independent LK waves.
+struct StreamArgs {
+    LkTable lk;
+    ShiftTable sh;
+    PyrArgs pyr;
+    CornerArgs corner;
+    // block 0 = corner wave; [1, pyr_first) LK (four waves per block); [pyr_first, sh_first) pyramid; [sh_first, end) shift.
+    // The LK blocks come first and are sized to ~85% of the resident-wave capacity: they all start at once and run for the
+    // whole launch, while the short staging blocks stream through the remaining slots underneath them.
+    int pyr_first, pyr_blocks_x, sh_first;
+};
 
-    // column validity: bytes outside [0,w) read as zero, derivatives there are zero
-    const bool ld_ok = cb >= 0 && cb < A.w;
-    uint32_t bmask = 0;
-    int cm[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool in = (cb + j) >= 0 && (cb + j) < A.w;
-        cm[j] = in ? -1 : 0;
-        bmask |= in ? (0xffu << (8 * j)) : 0u;
-    }
-    const uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
-
-    // rows outside the image are the zero border; rows past the last one this strip needs (the loop prefetches one
-    // row ahead) or outside the buffer are never dereferenced.  The row test is wave-uniform (scalar branch); lanes
-    // whose columns lie outside the image read column 0 of the row and are zeroed by bmask.
-    const int y_lim = min(min(ye + R + 1, A.h), A.row_end);
-    const int y_min = max(0, A.row0);
-    auto load_row = [&](const uint8_t *img, int y) -> uint32_t {
-        uint32_t v = 0u;
-        if (y >= y_min && y < y_lim) {
-            const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch; // scalar
-            v = *reinterpret_cast<const uint32_t *>(row + col_off);
-        }
-        return v & bmask;
-    };
-
-    // Two 3-row windows march down the strip NS rows apart: `in` around the derivative row entering the vertical
-    // window, `out` around the row leaving it.  The leaving row's derivatives are recomputed from the image (its rows
-    // are L2-resident: this wave read them NS steps ago) instead of being kept in an LDS ring: that costs one more
-    // derivative stage per step but no LDS, no pack/unpack of 16-bit fields, and it lets occupancy follow VGPRs only.
-    // Row r of either window lives in slot (r - (y_first - 1)) mod 3, so the loop is unrolled three times and every
-    // slot index is a compile-time constant (no register-to-register rotation).
-    const int y_first = ys - R; // first derivative row this strip needs
-    const int nsteps = (ye - ys) + 2 * R;
-    Row<MODE> win[3], wout[3];
-    {
-        const uint32_t p0 = load_row(A.prev, y_first - 1), n0 = load_row(A.next, y_first - 1);
-        const uint32_t p1 = load_row(A.prev, y_first), n1 = load_row(A.next, y_first);
-        unpack(p0, n0, win[0]);
-        unpack(p1, n1, win[1]);
-        wout[0] = win[0];
-        wout[1] = win[1];
-    }
-    uint32_t pf_ip = load_row(A.prev, y_first + 1), pf_in = load_row(A.next, y_first + 1);
-    uint32_t pf_op = pf_ip, pf_on = pf_in;
-
-    int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
-
-    auto body = [&](auto K, int s) {
-        constexpr int k = decltype(K)::value;               // s mod 3
-        constexpr int ko = ((k - NS % 3) % 3 + 3) % 3;      // (s - NS) mod 3
-        const int yy = y_first + s;                         // derivative row entering the window
-        const int yo = yy - NS;                             // derivative row leaving it
-        const bool have_out = s >= NS;
-
-        // take the prefetched rows, prefetch the next ones (consumed one step from now)
-        unpack(pf_ip, pf_in, win[(k + 2) % 3]);
-        pf_ip = load_row(A.prev, yy + 2);
-        pf_in = load_row(A.next, yy + 2);
-        if (have_out) {
-            unpack(pf_op, pf_on, wout[(ko + 2) % 3]);
-            pf_op = load_row(A.prev, yo + 2);
-            pf_on = load_row(A.next, yo + 2);
-        }
-
-        float ix[4], iy[4], it[4];
-        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182)
-        const int rvi = (yy >= 0 && yy < A.h) ? -1 : 0;
-        const int cmi[4] = {cm[0] & rvi, cm[1] & rvi, cm[2] & rvi, cm[3] & rvi};
-        derivs(win[k], win[(k + 1) % 3], win[(k + 2) % 3], cmi, ix, iy, it);
-        if (have_out) {
-            float ox[4], oy[4], ot[4];
-            const int rvo = (yo >= 0 && yo < A.h) ? -1 : 0;
-            const int cmo[4] = {cm[0] & rvo, cm[1] & rvo, cm[2] & rvo, cm[3] & rvo};
-            derivs(wout[ko], wout[(ko + 1) % 3], wout[(ko + 2) % 3], cmo, ox, oy, ot);
-            accumulate<true>(ix, iy, it, ox, oy, ot, vxx, vyy, vxy, vxt, vyt);
-        } else {
-            accumulate<false>(ix, iy, it, ix, iy, it, vxx, vyy, vxy, vxt, vyt);
-        }
-
-        // ---- emit output row y = yy - R ------------------------------------------------------------------------
-        if (s >= 2 * R) {
-            const int y = yy - R;
-            int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
-            hbox4<R>(vxx, hxx);
-            hbox4<R>(vyy, hyy);
-            hbox4<R>(vxy, hxy);
-            hbox4<R>(vxt, hxt);
-            hbox4<R>(vyt, hyt);
-            const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
-            if (out_lane) {
-                const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
-                const size_t pix = rowpix + (uint32_t)cb;
-                if constexpr (SUMS) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (cb + j < A.w) {
-                            A.sums[pix + j] = hxx[j];
-                            A.sums[A.sums_plane + pix + j] = hyy[j];
-                            A.sums[2 * A.sums_plane + pix + j] = hxy[j];
-                            A.sums[3 * A.sums_plane + pix + j] = hxt[j];
-                            A.sums[4 * A.sums_plane + pix + j] = hyt[j];
-                        }
-                    }
-                } else {
-                    float uv[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
-                    float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
-                    if (cb + 3 < A.w) {
-                        // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
-                        float2 *d2 = reinterpret_cast<float2 *>(dst);
-                        d2[0] = make_float2(uv[0], uv[1]);
-                        d2[1] = make_float2(uv[2], uv[3]);
-                        d2[2] = make_float2(uv[4], uv[5]);
-                        d2[3] = make_float2(uv[6], uv[7]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (cb + j < A.w) {
-                                dst[2 * j] = uv[2 * j];
-                                dst[2 * j + 1] = uv[2 * j + 1];
-                            }
-                    }
-                }
-            }
-        }
-    };
-
-    int s = 0;
-    while (true) {
-        body(std::integral_constant<int, 0>{}, s);
-        if (++s >= nsteps) break;
-        body(std::integral_constant<int, 1>{}, s);
-        if (++s >= nsteps) break;
-        body(std::integral_constant<int, 2>{}, s);
-        if (++s >= nsteps) break;
+template <int R, int MODE>
+__global__ __launch_bounds__(256, 3) void stream_kernel(const StreamArgs S)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (b == 0) {
+        if (S.corner.levels > 0 && tid < 64) corner_wave<MODE>(S.corner, tid, reinterpret_cast<float *>(lds));
+    } else if (b < S.pyr_first) {
+        // readfirstlane: the wave index is uniform, and everything derived from it (strip rows, row pointers, loop
+        // counters) must live in SGPRs as it does in the stand-alone kernel
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lk_wave<R, MODE, false>(S.lk, 4 * (b - 1) + wv, tid & 63);
+    } else if (b < S.sh_first) {
+        const int pb = b - S.pyr_first;
+        pyramid_block(S.pyr, pb % S.pyr_blocks_x, pb / S.pyr_blocks_x, tid, lds);
+    } else {
+        shift_block(S.sh, b - S.sh_first, tid);
     }
 }
 
@@ -462,23 +88,14 @@ int env_int(const char *name, int dflt)
     return e && atoi(e) > 0 ? atoi(e) : dflt;
 }
 
-template <int R, int MODE, bool SUMS>
-int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
+// One strip height for all levels (so all waves run about equally long): the smallest that keeps the wave count within
+// ~95% of `capacity` (waves resident at once), but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
+// The grid is sized to fit in ONE residency round: every wave runs for the whole kernel, so a second, partly filled
+// round would nearly double the run time.
+template <int R>
+int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
 {
     using G = TileGeom<R>;
-    // Waves that can be resident at once.  The grid is sized to fit in ONE round: every wave runs for the whole
-    // kernel, so a second, partly filled round would nearly double the run time.
-    static const int capacity = [] {
-        int dev = 0, cus = 256, per_cu = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lk_level_kernel<R, MODE, SUMS>, 64, 0) != hipSuccess || per_cu <= 0)
-            per_cu = 8;
-        (void)hipGetLastError();
-        return env_int("OFX_LK_TARGET_WAVES", cus * per_cu);
-    }();
-    // One strip height for all levels (so all waves run about equally long): the smallest that keeps the wave count
-    // within ~95% of capacity, but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
     const int min_h = env_int("OFX_LK_MIN_STRIP", 8);
     int max_rows = 1;
     for (int i = 0; i < n; ++i) max_rows = lv[i].rows_out > max_rows ? lv[i].rows_out : max_rows;
@@ -499,9 +116,69 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
         blocks += t.lv[i].tiles_x * ofx_div_up(lv[i].rows_out, t.lv[i].strip_h);
     }
     t.first_block[n] = blocks;
+    *out = t;
+    return blocks;
+}
+
+template <typename K>
+int resident_waves(K kernel, int threads, size_t lds)
+{
+    int dev = 0, cus = 256, per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu <= 0) per_cu = 8 * 64 / threads;
+    (void)hipGetLastError();
+    return env_int("OFX_LK_TARGET_WAVES", cus * per_cu * (threads / 64));
+}
+
+template <int R, int MODE, bool SUMS>
+int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
+{
+    static const int capacity = resident_waves(lk_level_kernel<R, MODE, SUMS>, 64, 0);
+    LkTable t{};
+    const int blocks = plan_table<R>(lv, n, capacity, &t);
     hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3((unsigned)blocks), dim3(64), 0, st, t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
+}
+
+template <int R, int MODE>
+int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, int sh_blocks, size_t lds, hipStream_t st)
+{
+    static const int capacity = resident_waves(stream_kernel<R, MODE>, 256, 16 * 1024) * env_int("OFX_STREAM_LK_PERCENT", 85) / 100;
+    int lk_blocks = 0;
+    if (n > 0) lk_blocks = ofx_div_up(plan_table<R>(lv, n, capacity, &S.lk), 4);
+    S.pyr_first = 1 + lk_blocks;
+    S.sh_first = S.pyr_first + pyr_blocks;
+    const int blocks = S.sh_first + sh_blocks;
+    if (lds < 2 * OFX_MAX_LEVELS * sizeof(float)) lds = 2 * OFX_MAX_LEVELS * sizeof(float); // the corner wave's scratch
+    hipLaunchKernelGGL((stream_kernel<R, MODE>), dim3((unsigned)blocks), dim3(256), lds, st, S);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+template <int MODE>
+int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, int pb, int sb, size_t lds, hipStream_t st)
+{
+    switch (radius) {
+    case 1: return launch_stream_r<1, MODE>(lv, n, S, pb, sb, lds, st);
+    case 2: return launch_stream_r<2, MODE>(lv, n, S, pb, sb, lds, st);
+    case 3: return launch_stream_r<3, MODE>(lv, n, S, pb, sb, lds, st);
+    case 4: return launch_stream_r<4, MODE>(lv, n, S, pb, sb, lds, st);
+    case 5: return launch_stream_r<5, MODE>(lv, n, S, pb, sb, lds, st);
+    case 6: return launch_stream_r<6, MODE>(lv, n, S, pb, sb, lds, st);
+    case 7: return launch_stream_r<7, MODE>(lv, n, S, pb, sb, lds, st);
+    case 8: return launch_stream_r<8, MODE>(lv, n, S, pb, sb, lds, st);
+    case 9: return launch_stream_r<9, MODE>(lv, n, S, pb, sb, lds, st);
+    case 10: return launch_stream_r<10, MODE>(lv, n, S, pb, sb, lds, st);
+    case 11: return launch_stream_r<11, MODE>(lv, n, S, pb, sb, lds, st);
+    default: break;
+    }
+    if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
+        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, pb, sb, lds, st);
+    }
+    ofx_set_error("ofx_stream_launch: window %d not supported in mode %d", 2 * radius + 1, MODE);
+    return OFX_E_UNSUPPORTED;
 }
 
 template <int MODE, bool SUMS>
@@ -528,13 +205,12 @@ int launch_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
     return OFX_E_UNSUPPORTED;
 }
 
-int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, void *stream)
+int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, LkLevelIn *lv, int *count)
 {
     OFX_REQUIRE(d != nullptr && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_lk_levels: bad descriptor count %d", n);
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_lk_level: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_lk_level: bad mode %d", mode);
     const int radius = window >> 1;
-    LkLevelIn lv[OFX_MAX_LEVELS];
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const ofx_geom *g = &d[i].geom;
@@ -548,6 +224,7 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
         LkArgs a{};
         a.prev = d[i].d_prev;
         a.next = d[i].d_next;
+        a.uv = d[i].d_uv;
         a.flow = d[i].d_flow;
         a.sums = d_sums;
         // plane stride of the inspection output = rows from flow_row0 to out_y1
@@ -564,7 +241,17 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
         lv[m].rows_out = rows_out;
         ++m;
     }
+    *count = m;
+    return OFX_OK;
+}
+
+int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, void *stream)
+{
+    LkLevelIn lv[OFX_MAX_LEVELS];
+    int m = 0;
+    OFX_TRY(lk_build_levels(d, n, window, mode, d_sums, lv, &m));
     if (m == 0) return OFX_OK;
+    const int radius = window >> 1;
     hipStream_t st = ofx_stream(stream);
     if (d_sums) {
         return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, true>(radius, lv, m, st)
@@ -576,6 +263,34 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
 
 } // namespace
 
+extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mode, void *stream)
+{
+    OFX_REQUIRE(g != nullptr, "ofx_stream_launch: null argument");
+    OFX_REQUIRE(window >= 3 && (window & 1), "ofx_stream_launch: window must be odd and >= 3 (got %d)", window);
+    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_stream_launch: bad mode %d", mode);
+    StreamArgs S{};
+    size_t lds = 0;
+    int pyr_blocks = 0, sh_blocks = 0;
+    if (g->pyr_levels >= 2) {
+        int bx = 0, by = 0;
+        OFX_TRY(ofx_pyramid_args(g->d_frame, g->frame_pitch, g->w, g->h, g->d_levels, g->pitches, g->pyr_levels, g->d_levels[0],
+                                 g->pitches[0], &S.pyr, &lds, &bx, &by));
+        S.pyr_blocks_x = bx;
+        pyr_blocks = bx * by;
+    } else {
+        S.pyr_blocks_x = 1;
+    }
+    if (g->corner_levels > 0) OFX_TRY(ofx_corner_args(g->corner, g->corner_levels, window, mode, g->d_uv, &S.corner));
+    if (g->n_shift > 0) OFX_TRY(ofx_shift_table(g->shift, g->n_shift, &S.sh, &sh_blocks));
+    LkLevelIn lv[OFX_MAX_LEVELS];
+    int m = 0;
+    if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
+    if (pyr_blocks == 0 && sh_blocks == 0 && m == 0 && g->corner_levels <= 0) return OFX_OK;
+    hipStream_t st = ofx_stream(stream);
+    return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, pyr_blocks, sh_blocks, lds, st)
+                                     : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, pyr_blocks, sh_blocks, lds, st);
+}
+
 extern "C" int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream)
 {
     return lk_dispatch(levels, n, window, mode, nullptr, stream);
@@ -585,7 +300,7 @@ extern "C" int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const 
                             float *d_flow, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_flow && g, "ofx_lk_level: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0};
+    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0, nullptr};
     return lk_dispatch(&d, 1, window, mode, nullptr, stream);
 }
 
@@ -593,6 +308,6 @@ extern "C" int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, c
                                  int32_t *d_sums5, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_sums5 && g, "ofx_lk_level_sums: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0};
+    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0, nullptr};
     return lk_dispatch(&d, 1, window, mode, d_sums5, stream);
 }

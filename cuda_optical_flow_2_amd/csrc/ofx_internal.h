@@ -42,3 +42,15 @@ int ofx_check_geom(const ofx_geom *g, const char *who);
 // rows of the level that a stencil of vertical radius `halo` around [out_y0,out_y1) touches, clipped to the image,
 // must be present in the buffer
 int ofx_check_halo(const ofx_geom *g, int halo, const char *who);
+
+// argument builders shared between the stand-alone stage launches and the stream (pipelined) launch; the structs live
+// in stages_body.h / corner_body.h
+namespace ofx_dev {
+struct PyrArgs;
+struct ShiftTable;
+struct CornerArgs;
+} // namespace ofx_dev
+int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
+                     uint8_t *d_level0_copy, int copy_pitch, ofx_dev::PyrArgs *out, size_t *lds_bytes, int *blocks_x, int *blocks_y);
+int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *out, int *blocks_out);
+int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, ofx_dev::CornerArgs *out);

@@ -1,59 +1,26 @@
 // Pyramid downsample, global shift, flow composition and layout helpers for gfx950.
 // All of these are pure streaming kernels (HBM-bound); they use 4-pixels-per-lane dword accesses where the layout
 // allows it and one wave-row mapping so that every load/store instruction touches one contiguous span.
-#include "ofx_internal.h"
+#include "stages_body.h"
+
+using namespace ofx_dev;
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------------------------
-// 2x decimating 3x3 Gaussian on a 1ch plane (OptFlowGpu.cu:1198-1232 / OptFlowCPU.cpp:112-148 with
-// GAUS_KERNEL_3x3 = [1 2 1]^T [1 2 1] / 16, kernels.cpp:61-64).  The reference accumulates in float and truncates;
-// with power-of-two weights and u8 inputs every partial sum is exact, so integer (sum >> 4) is bit-identical.
-// Source taps at column/row -1 are outside the image and skipped; taps 2x+1 <= 2w-1 are always inside.
-// A lane produces 4 destination pixels from source columns 8c-1 .. 8c+7.
-struct DownArgs {
-    const uint8_t *src;
-    uint8_t *dst;
-    int src_pitch, src_row0, src_row_end; // source buffer holds source rows [src_row0, src_row_end)
-    int dw, dh, dst_pitch, dst_row0;      // destination level geometry
-    int out_y0, out_y1;
-};
-
 __global__ __launch_bounds__(256) void downsample_1ch_kernel(const DownArgs A)
 {
-    const int c4 = blockIdx.x * blockDim.x + threadIdx.x; // group of 4 destination columns
-    const int y = A.out_y0 + blockIdx.y;
-    const int x0 = 4 * c4;
-    if (x0 >= A.dw || y >= A.out_y1) return;
-    const int sw = 2 * A.dw;
-    int col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // vertical [1 2 1] of source columns 8c-1 .. 8c+7
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        const int sy = 2 * y - 1 + p;
-        if (sy < 0 || sy < A.src_row0 || sy >= A.src_row_end) continue; // sy < 2*dh always
-        const int wgt = (p == 1) ? 2 : 1;
-        const uint8_t *row = A.src + (size_t)(sy - A.src_row0) * (size_t)A.src_pitch;
-        const int sx = 2 * x0; // multiple of 8
-        uint32_t lo = 0, hi = 0;
-        // the source pitch is a multiple of 4 and >= sw, and sx < sw, so both dwords stay inside the row pitch
-        lo = *reinterpret_cast<const uint32_t *>(row + sx);
-        if (sx + 4 < A.src_pitch) hi = *reinterpret_cast<const uint32_t *>(row + sx + 4);
-        const int left = (sx > 0) ? row[sx - 1] : 0;
-        col[0] += wgt * left;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int a = (lo >> (8 * k)) & 0xff, b = (hi >> (8 * k)) & 0xff;
-            col[1 + k] += wgt * ((sx + k < sw) ? a : 0);
-            col[5 + k] += wgt * ((sx + 4 + k < sw) ? b : 0);
-        }
-    }
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int v = (col[2 * k] + 2 * col[2 * k + 1] + col[2 * k + 2]) >> 4;
-        out |= (uint32_t)((x0 + k < A.dw) ? v : 0) << (8 * k); // pitch padding is written as zero
-    }
-    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.dst_row0) * (size_t)A.dst_pitch + x0) = out;
+    downsample_rows(A, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)blockIdx.y);
+}
+
+__global__ __launch_bounds__(kPyrThreads) void pyramid_fused_kernel(const PyrArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    pyramid_block(A, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds);
+}
+
+__global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftTable T)
+{
+    shift_block(T, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // 3-channel variant, one thread per destination pixel (API-compat path only: gpu::gauss_pyramid on colour images)
@@ -103,59 +70,6 @@ __global__ void shift_vector_kernel(const FlowPtrs P, int level, int max_level, 
     }
     uv[0] = u;
     uv[1] = v;
-}
-
-// cpu::shift_back_pyramid on channel 0 (OptFlowCPU.cpp:247, :268-279), destination zero-initialised:
-//   target = ((int)(x+u), (int)(y+v)) with float add and truncation toward zero; inside the image -> copy;
-//   outside (or non-finite) -> the byte the leading memcpy of w*h bytes left there: the pixel's own value when
-//   3*(y*w+x) < w*h, else 0.
-struct ShiftArgs {
-    const uint8_t *src;
-    uint8_t *dst;
-    const float *uv;
-    int w, h, pitch, row0, row_end, out_y0, out_y1, blocks_x;
-};
-
-struct ShiftTable {
-    ShiftArgs lv[OFX_MAX_LEVELS];
-    int first_block[OFX_MAX_LEVELS + 1];
-    int n;
-};
-
-__global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftTable T)
-{
-    int level = 0;
-    while (level + 1 < T.n && (int)blockIdx.x >= T.first_block[level + 1]) ++level;
-    const ShiftArgs &A = T.lv[level];
-    const int block = (int)blockIdx.x - T.first_block[level];
-    const int bx = block % A.blocks_x, by = block / A.blocks_x;
-    const int x0 = 4 * (bx * (int)blockDim.x + (int)threadIdx.x);
-    const int y = A.out_y0 + by;
-    if (x0 >= A.pitch || y >= A.out_y1) return;
-    const float u = A.uv[0], v = A.uv[1];
-    const float ty = (float)y + v;
-    const bool yin = ty > -1.0f && ty < (float)A.h;
-    const int ny = yin ? (int)ty : 0;
-    const bool yhave = ny >= A.row0 && ny < A.row_end;
-    const uint8_t *srow = A.src + (size_t)((yhave ? ny : A.row0) - A.row0) * (size_t)A.pitch;
-    const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
-    const long long third = (long long)A.w * (long long)A.h;
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int x = x0 + k;
-        int val = 0;
-        if (x < A.w) {
-            const float tx = (float)x + u;
-            if (yin && yhave && tx > -1.0f && tx < (float)A.w) {
-                val = srow[(int)tx];
-            } else {
-                val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
-            }
-        }
-        out |= (uint32_t)val << (8 * k);
-    }
-    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -237,6 +151,61 @@ extern "C" int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_r
     return OFX_OK;
 }
 
+// Fills the arguments of the fused pyramid stage; returns the dynamic LDS it needs and its grid (shared with the
+// stream kernel's launcher in lk_level.hip).
+int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
+                     uint8_t *d_level0_copy, int copy_pitch, PyrArgs *out, size_t *lds_bytes, int *blocks_x, int *blocks_y)
+{
+    OFX_REQUIRE(d_level0 && d_levels && pitches && w > 0 && h > 0, "ofx_pyramid_1ch: bad arguments");
+    OFX_REQUIRE(levels >= 2 && levels - 1 <= kPyrMaxProduced, "ofx_pyramid_1ch: %d levels unsupported (2..%d)", levels,
+                kPyrMaxProduced + 1);
+    OFX_REQUIRE(((uintptr_t)d_level0 & 3) == 0 && (pitch0 & 3) == 0, "ofx_pyramid_1ch: level 0 must be 4-byte aligned with a pitch multiple of 4");
+    PyrArgs a{};
+    a.src = d_level0;
+    a.pitch[0] = pitch0;
+    a.w[0] = w;
+    a.h[0] = h;
+    a.n = levels - 1;
+    a.dst[0] = d_level0_copy;
+    a.dst0_pitch = copy_pitch;
+    for (int k = 1; k < levels; ++k) {
+        OFX_REQUIRE(((w >> (k - 1)) & 1) == 0 && ((h >> (k - 1)) & 1) == 0, "ofx_pyramid_1ch: level %d has odd dimensions", k - 1);
+        OFX_REQUIRE(d_levels[k] != nullptr && pitches[k] >= (w >> k), "ofx_pyramid_1ch: bad plane for level %d", k);
+        a.dst[k] = d_levels[k];
+        a.pitch[k] = pitches[k];
+        a.w[k] = w >> k;
+        a.h[k] = h >> k;
+    }
+    const int H0 = (1 << a.n) - 1;
+    // two LDS areas used alternately: even levels in area 0, odd levels in area 1
+    size_t area[2] = {0, 0};
+    for (int k = 1; k <= a.n; ++k) { // level 0 is read from HBM directly, levels 1..n live in LDS
+        const int r = (kPyrTile >> k) + (H0 >> k);
+        a.stride[k] = (r + 3) & ~3;
+        const size_t bytes = (size_t)a.stride[k] * (size_t)(r + 1);
+        if (bytes > area[k & 1]) area[k & 1] = bytes;
+    }
+    area[0] = (area[0] + 15) & ~(size_t)15;
+    for (int k = 0; k <= a.n; ++k) a.lds_off[k] = (k & 1) ? (int)area[0] : 0;
+    *lds_bytes = area[0] + ((area[1] + 15) & ~(size_t)15);
+    *blocks_x = ofx_div_up(w, kPyrTile);
+    *blocks_y = ofx_div_up(h, kPyrTile);
+    *out = a;
+    return OFX_OK;
+}
+
+extern "C" int ofx_pyramid_1ch(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches,
+                               int levels, void *stream)
+{
+    PyrArgs a{};
+    size_t lds_bytes = 0;
+    int bx = 0, by = 0;
+    OFX_TRY(ofx_pyramid_args(d_level0, pitch0, w, h, d_levels, pitches, levels, nullptr, 0, &a, &lds_bytes, &bx, &by));
+    hipLaunchKernelGGL(pyramid_fused_kernel, dim3(bx, by), dim3(kPyrThreads), lds_bytes, ofx_stream(stream), a);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 extern "C" int ofx_downsample_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int dw, int dh, void *stream)
 {
     OFX_REQUIRE(d_src3 && d_dst3 && dw > 0 && dh > 0, "ofx_downsample_3ch: bad arguments");
@@ -261,7 +230,7 @@ extern "C" int ofx_shift_vector(const float *const *d_flow_levels, int level, in
     return OFX_OK;
 }
 
-extern "C" int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream)
+int ofx_shift_table(const ofx_shift_desc *levels, int n, ShiftTable *out, int *blocks_out)
 {
     OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_shift_levels: bad descriptor count %d", n);
     ShiftTable t{};
@@ -280,9 +249,19 @@ extern "C" int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *strea
         blocks += bx * (g->out_y1 - g->out_y0);
         ++m;
     }
-    if (m == 0) return OFX_OK;
     t.n = m;
     t.first_block[m] = blocks;
+    *out = t;
+    *blocks_out = blocks;
+    return OFX_OK;
+}
+
+extern "C" int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream)
+{
+    ShiftTable t{};
+    int blocks = 0;
+    OFX_TRY(ofx_shift_table(levels, n, &t, &blocks));
+    if (blocks == 0) return OFX_OK;
     hipLaunchKernelGGL(shift_1ch_kernel, dim3((unsigned)blocks), dim3(256), 0, ofx_stream(stream), t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;

@@ -22,7 +22,22 @@ struct ofx_session {
     int own0[OFX_MAX_LEVELS]{}, own1[OFX_MAX_LEVELS]{}; // rows this rank computes
     int buf0[OFX_MAX_LEVELS]{}, buf1[OFX_MAX_LEVELS]{}; // rows the plane buffers hold
     int cmp0[OFX_MAX_LEVELS]{}, cmp1[OFX_MAX_LEVELS]{}; // rows this rank downsamples itself
-    uint8_t *plane[3][OFX_MAX_LEVELS]{};                // 0 prev, 1 next, 2 shifted scratch
+    // storage: three image sets rotate through the roles prev -> (free) -> next, two shifted-scratch sets alternate, so
+    // that the pipelined path can build frame i+1's pyramid / corner / shift while pair i's LK launch is running
+    uint8_t *img[5][OFX_MAX_LEVELS]{};                  // sets 0..2 rotate in the pair-at-a-time paths, all 5 in the stream pipeline
+    uint8_t *sh[2][OFX_MAX_LEVELS]{};
+    int cur = 0, sht = 0;                               // img[cur] = previous frame, img[(cur+1)%3] = next frame
+    uint8_t *plane[3][OFX_MAX_LEVELS]{};                // role view: 0 prev, 1 next, 2 shifted scratch
+    hipStream_t aux = nullptr;                          // pipelined path: staging stream owned by the session
+    hipEvent_t ev_ready = nullptr;                      // staging of the next pair finished (aux -> main)
+    hipEvent_t ev_set_done[3] = {nullptr, nullptr, nullptr}; // last LK launch that read img[i] as `prev` finished
+    bool set_busy[3] = {false, false, false};
+    bool staged = false;
+    long stream_n = -1;      // ticks of the stream pipeline so far (-1: not streaming)
+    long stream_frames = -1; // total frames, known once draining starts (-1: still receiving)
+    // index of the newest frame whose pyramid exists once tick f has been issued
+    long stream_last_frame(long f, bool has_frame) const { return stream_frames >= 0 ? stream_frames - 1 : (has_frame ? f : f - 1); }
+    int pitch0_next() const { return pitch[0]; }
     float *flow[OFX_MAX_LEVELS]{};
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
@@ -34,6 +49,15 @@ struct ofx_session {
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
 };
+
+static void repoint(ofx_session *s)
+{
+    for (int k = 0; k < s->p.levels; ++k) {
+        s->plane[0][k] = s->img[s->cur][k];
+        s->plane[1][k] = s->img[(s->cur + 1) % 3][k];
+        s->plane[2][k] = s->sh[s->sht][k];
+    }
+}
 
 static ofx_geom level_geom(const ofx_session *s, int k, int out0, int out1)
 {
@@ -68,7 +92,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(s != nullptr, "ofx_session_create: out of host memory");
     s->p = *p;
     size_t total = 0;
-    std::vector<size_t> off_plane[3], off_flow;
+    std::vector<size_t> off_plane[7], off_flow;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
         s->h[k] = p->height >> k;
@@ -96,7 +120,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
-        for (int t = 0; t < 3; ++t) {
+        for (int t = 0; t < 7; ++t) { // 5 image sets + 2 shifted sets
             off_plane[t].push_back(total);
             total += plane_bytes;
         }
@@ -105,7 +129,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         total += align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
     }
     const size_t off_uv = total;
-    total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float), kAlign);
+    total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * 2, kAlign); // two sets (the stream pipeline alternates)
     const size_t off_staging = total;
     total += align_up((size_t)p->width * (size_t)p->height * 3, kAlign);
 
@@ -125,11 +149,13 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     }
     uint8_t *base = static_cast<uint8_t *>(s->arena);
     for (int k = 0; k < p->levels; ++k) {
-        for (int t = 0; t < 3; ++t) s->plane[t][k] = base + off_plane[t][k];
+        for (int t = 0; t < 5; ++t) s->img[t][k] = base + off_plane[t][k];
+        for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[5 + t][k];
         s->flow[k] = reinterpret_cast<float *>(base + off_flow[k]);
     }
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = base + off_staging;
+    repoint(s);
     *out = s;
     return OFX_OK;
 }
@@ -139,6 +165,11 @@ extern "C" int ofx_session_destroy(ofx_session *s)
     if (!s) return OFX_OK;
     hipError_t e = hipSuccess;
     for (hipEvent_t ev : s->ev) (void)hipEventDestroy(ev);
+    (void)hipSetDevice(s->p.device);
+    if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
+    for (hipEvent_t ev : s->ev_set_done)
+        if (ev) (void)hipEventDestroy(ev);
+    if (s->aux) (void)hipStreamDestroy(s->aux);
     if (s->arena) {
         (void)hipSetDevice(s->p.device);
         e = hipFree(s->arena);
@@ -196,6 +227,22 @@ extern "C" int ofx_session_downsample_level(ofx_session *s, int k, void *stream)
                               s->plane[1][k], &g, stream);
 }
 
+static int build_pyramid(ofx_session *s, void *stream)
+{
+    if (s->p.levels == 1) return OFX_OK;
+    if (!s->p.sharded && s->p.levels - 1 <= 6) { // whole levels: one fused launch
+        uint8_t *lv[OFX_MAX_LEVELS] = {};
+        int pitches[OFX_MAX_LEVELS] = {};
+        for (int k = 1; k < s->p.levels; ++k) {
+            lv[k] = s->plane[1][k];
+            pitches[k] = s->pitch[k];
+        }
+        return ofx_pyramid_1ch(s->plane[1][0], s->pitch0_next(), s->w[0], s->h[0], lv, pitches, s->p.levels, stream);
+    }
+    for (int k = 1; k < s->p.levels; ++k) OFX_TRY(ofx_session_downsample_level(s, k, stream));
+    return OFX_OK;
+}
+
 extern "C" int ofx_session_build_pyramid(ofx_session *s, void *stream)
 {
     OFX_REQUIRE(s, "ofx_session_build_pyramid: null session");
@@ -203,8 +250,7 @@ extern "C" int ofx_session_build_pyramid(ofx_session *s, void *stream)
         ofx_set_error("ofx_session_build_pyramid: no frame loaded");
         return OFX_E_STATE;
     }
-    for (int k = 1; k < s->p.levels; ++k) OFX_TRY(ofx_session_downsample_level(s, k, stream));
-    return OFX_OK;
+    return build_pyramid(s, stream);
 }
 
 extern "C" int ofx_session_compute_uv(ofx_session *s, int level, void *stream)
@@ -291,34 +337,20 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
     }
     ofx_lk_desc d[OFX_MAX_LEVELS];
     for (int k = 0; k < s->p.levels; ++k)
-        d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k]};
+        d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr};
     return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv, stream);
 }
 
-// Every level's shift in one launch, then every level's fused LK in one launch, using the uv slots as they stand.
-extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
+// Every level's fused LK in one launch, using the uv slots as they stand; below the top level the kernel reads `next`
+// through the global shift (no separate shift pass, no shifted planes).
+static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
 {
-    OFX_REQUIRE(s, "ofx_session_run_levels: null session");
-    if (!s->have_prev || !s->have_next) {
-        ofx_set_error("ofx_session_run_levels: need a previous and a next frame");
-        return OFX_E_STATE;
-    }
-    const int L = s->p.levels, halo = (s->p.window >> 1) + 1;
-    ofx_shift_desc sh[OFX_MAX_LEVELS];
+    const int L = s->p.levels;
     ofx_lk_desc lk[OFX_MAX_LEVELS];
-    int ns = 0, nl = 0;
-    for (int k = L - 1; k >= 0; --k) { // coarse levels first: their few waves start at once and finish early
-        const uint8_t *next = s->plane[1][k];
-        if (k != L - 1) {
-            int y0 = s->own0[k] - halo, y1 = s->own1[k] + halo;
-            if (y0 < s->buf0[k]) y0 = s->buf0[k];
-            if (y1 > s->buf1[k]) y1 = s->buf1[k];
-            sh[ns++] = ofx_shift_desc{s->plane[1][k], s->plane[2][k], level_geom(s, k, y0, y1), s->uv + 2 * k};
-            next = s->plane[2][k];
-        }
-        lk[nl++] = ofx_lk_desc{s->plane[0][k], next, level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k]};
-    }
-    if (ns) OFX_TRY(ofx_shift_levels(sh, ns, stream));
+    int nl = 0;
+    for (int k = L - 1; k >= 0; --k) // coarse levels first: their few waves start at once and finish early
+        lk[nl++] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k],
+                               k == L - 1 ? nullptr : uv + 2 * k};
     const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
     if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
     OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
@@ -327,6 +359,16 @@ extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
         s->ev_used += 2;
     }
     return OFX_OK;
+}
+
+extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_run_levels: null session");
+    if (!s->have_prev || !s->have_next) {
+        ofx_set_error("ofx_session_run_levels: need a previous and a next frame");
+        return OFX_E_STATE;
+    }
+    return lk_all_levels(s, s->uv, stream);
 }
 
 extern "C" int ofx_session_run_flow(ofx_session *s, void *stream)
@@ -352,14 +394,107 @@ extern "C" int ofx_session_run_flow_sequential(ofx_session *s, void *stream)
 extern "C" int ofx_session_swap(ofx_session *s)
 {
     OFX_REQUIRE(s, "ofx_session_swap: null session");
-    for (int k = 0; k < s->p.levels; ++k) {
-        uint8_t *t = s->plane[0][k];
-        s->plane[0][k] = s->plane[1][k];
-        s->plane[1][k] = t;
-    }
+    s->cur = (s->cur + 1) % 3;
+    repoint(s);
     s->have_prev = s->have_next;
     s->have_next = false;
+    s->staged = false;
     return OFX_OK;
+}
+
+// ---- pipelined path ---------------------------------------------------------------------------------------------------
+// A pair is split in two halves that run on different streams:
+//   staging (aux stream):  load the new frame, build its pyramid, corner flows, shift of every level
+//   solve   (main stream): the multi-level LK launch
+// The LK launch of pair i is VALU-bound and fills the chip; the staging kernels of pair i+1 are small and latency-bound,
+// so running them underneath it hides them almost entirely.  Hazards are covered by two events: `ev_ready` (staging ->
+// LK of the same pair) and `ev_set_done[x]` (LK that read image set x as `prev` -> the staging that overwrites set x two
+// pairs later; the same event also orders the reuse of the shifted-scratch set).
+static int ensure_pipeline(ofx_session *s)
+{
+    if (s->ev_ready) return OFX_OK;
+    OFX_HIP(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) OFX_HIP(hipEventCreateWithFlags(&s->ev_set_done[i], hipEventDisableTiming));
+    // highest priority: the staging kernels are tiny and must slip in between the LK waves of the previous pair
+    int prio_lo = 0, prio_hi = 0;
+    OFX_HIP(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    OFX_HIP(hipStreamCreateWithPriority(&s->aux, hipStreamNonBlocking, prio_hi));
+    return OFX_OK;
+}
+
+extern "C" int ofx_session_aux_stream(ofx_session *s, void **stream)
+{
+    OFX_REQUIRE(s && stream, "ofx_session_aux_stream: null argument");
+    OFX_TRY(ensure_pipeline(s));
+    *stream = s->aux;
+    return OFX_OK;
+}
+
+// staging, part 1: frame -> next image set, pyramid.  `d_gray1` must be complete in HBM when this is called.
+extern "C" int ofx_session_stage_frame(ofx_session *s, const uint8_t *d_gray1, int pitch, void *aux_stream)
+{
+    OFX_REQUIRE(s && d_gray1, "ofx_session_stage_frame: null argument");
+    OFX_REQUIRE(pitch >= s->w[0], "ofx_session_stage_frame: pitch %d < width %d", pitch, s->w[0]);
+    if (!s->have_prev) {
+        ofx_set_error("ofx_session_stage_frame: no previous frame (load, build, swap first)");
+        return OFX_E_STATE;
+    }
+    OFX_TRY(ensure_pipeline(s));
+    hipStream_t aux = aux_stream ? ofx_stream(aux_stream) : s->aux;
+    const int nxt = (s->cur + 1) % 3;
+    if (s->set_busy[nxt]) OFX_HIP(hipStreamWaitEvent(aux, s->ev_set_done[nxt], 0));
+    OFX_TRY(load_level0(s, d_gray1, false, pitch, aux));
+    return build_pyramid(s, aux);
+}
+
+// staging, part 2 (after the corner flows / the broadcast of the shift vectors): signal the solve half.  (The shift
+// itself is fused into the LK launch; the name is kept from when it was a separate pass.)
+extern "C" int ofx_session_stage_shift(ofx_session *s, void *aux_stream)
+{
+    OFX_REQUIRE(s, "ofx_session_stage_shift: null session");
+    if (!s->have_prev || !s->have_next) {
+        ofx_set_error("ofx_session_stage_shift: stage a frame first");
+        return OFX_E_STATE;
+    }
+    OFX_TRY(ensure_pipeline(s));
+    hipStream_t aux = aux_stream ? ofx_stream(aux_stream) : s->aux;
+    OFX_HIP(hipEventRecord(s->ev_ready, aux));
+    s->staged = true;
+    return OFX_OK;
+}
+
+// solve half: one multi-level LK launch on the caller's stream, then the staged frame becomes the previous frame.
+extern "C" int ofx_session_solve_staged(ofx_session *s, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_solve_staged: null session");
+    if (!s->staged) {
+        ofx_set_error("ofx_session_solve_staged: nothing staged (stage_frame, corner_flows, stage_shift first)");
+        return OFX_E_STATE;
+    }
+    hipStream_t st = ofx_stream(stream);
+    OFX_HIP(hipStreamWaitEvent(st, s->ev_ready, 0));
+    // the shift vectors of this pair are copied out of the shared slot on the solve stream's side: the next pair's
+    // corner kernel (aux stream) overwrites the slot while this LK launch may still be reading it
+    float *uv_pair = s->uv + 2 * OFX_MAX_LEVELS;
+    OFX_HIP(hipMemcpyAsync(uv_pair, s->uv, 2 * OFX_MAX_LEVELS * sizeof(float), hipMemcpyDeviceToDevice, st));
+    OFX_TRY(lk_all_levels(s, uv_pair, stream));
+    OFX_HIP(hipEventRecord(s->ev_set_done[s->cur], st));
+    s->set_busy[s->cur] = true;
+    return ofx_session_swap(s);
+}
+
+// Whole pair, pipelined: staging on the session's aux stream, solve on `stream`; on return the new frame is the
+// previous frame.  Equivalent to set_frame_device + build_pyramid + run_flow + swap, bit for bit.
+extern "C" int ofx_session_submit_device(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream)
+{
+    OFX_REQUIRE(s, "ofx_session_submit_device: null session");
+    OFX_REQUIRE(!s->p.sharded || s->buf0[0] == 0, "ofx_session_submit_device: on a sharded session drive the halves yourself "
+                                                   "(stage_frame, corner_flows on the rank holding row 0, broadcast, stage_shift, "
+                                                   "solve_staged)");
+    OFX_TRY(ofx_session_stage_frame(s, d_gray1, pitch, nullptr));
+    OFX_TRY(ofx_session_corner_flows(s, s->aux));
+    OFX_TRY(ofx_session_stage_shift(s, nullptr));
+    return ofx_session_solve_staged(s, stream);
 }
 
 extern "C" int ofx_session_plane(ofx_session *s, int which, int level, uint8_t **d_ptr, ofx_geom *geom)
@@ -394,6 +529,106 @@ extern "C" int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst
     OFX_HIP(hipMemcpyAsync(h_dst, s->flow[level], bytes, hipMemcpyDeviceToHost, st));
     OFX_HIP(hipStreamSynchronize(st));
     return OFX_OK;
+}
+
+// ---- stream pipeline: one launch per frame ---------------------------------------------------------------------------
+// Frame f (0-based) submitted at tick f; tick f runs  pyramid(frame f) | corner(pair f-1) | LK(pair f-2, shift fused)
+// where pair p is (frame p-1 -> frame p).  Frame f lives in image set f mod 5 and pair p's shift vectors in slot p mod 2,
+// which makes every stage of a tick independent of the others; ticks are ordered by the stream.  The flow of pair p is
+// complete after tick p+2.
+extern "C" int ofx_session_stream_begin(ofx_session *s)
+{
+    OFX_REQUIRE(s, "ofx_session_stream_begin: null session");
+    OFX_REQUIRE(!s->p.sharded, "ofx_session_stream_begin: the stream pipeline runs whole frames; shard with the staged API");
+    OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
+    s->stream_n = 0;
+    s->have_prev = s->have_next = s->staged = false;
+    return OFX_OK;
+}
+
+static int stream_tick(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair)
+{
+    const long f = s->stream_n; // index of the frame arriving with this tick (if any)
+    const int L = s->p.levels, halo = (s->p.window >> 1) + 1;
+    float *uvset[2] = {s->uv, s->uv + 2 * OFX_MAX_LEVELS};
+    auto set_of = [&](long frame) { return (int)(frame % 5); };
+    ofx_stream_stages g;
+    memset(&g, 0, sizeof g);
+    if (d_gray1) { // pyramid(frame f)
+        OFX_REQUIRE(pitch >= s->w[0] && (pitch & 3) == 0 && ((uintptr_t)d_gray1 & 3) == 0,
+                    "ofx_session_stream_submit: frame must be 4-byte aligned with a pitch multiple of 4 and >= width");
+        g.d_frame = d_gray1;
+        g.frame_pitch = pitch;
+        g.w = s->w[0];
+        g.h = s->h[0];
+        g.pyr_levels = L;
+        for (int k = 0; k < L; ++k) {
+            g.d_levels[k] = s->img[set_of(f)][k];
+            g.pitches[k] = s->pitch[k];
+        }
+    }
+    const long pc = f - 1; // corner(pair pc): frames pc-1 -> pc, both pyramids complete since the previous tick
+    if (pc >= 1 && pc <= s->stream_last_frame(f, d_gray1 != nullptr)) {
+        g.corner_levels = L;
+        g.d_uv = uvset[pc & 1];
+        for (int k = 0; k < L; ++k)
+            g.corner[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr};
+    }
+    const long pl = f - 2; // LK(pair pl), reading next through the shift vectors the previous tick's corner stage wrote
+    *completed_pair = -1;
+    if (pl >= 1 && pl <= s->stream_last_frame(f, d_gray1 != nullptr)) {
+        for (int k = L - 1; k >= 0; --k)
+            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0,
+                                         k == L - 1 ? nullptr : uvset[pl & 1] + 2 * k};
+        *completed_pair = (int)pl;
+    }
+    (void)halo;
+    static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }(); // timing experiments only
+    if (skip & 1) g.pyr_levels = 0;
+    if (skip & 2) g.corner_levels = 0;
+    if (skip & 8) g.n_lk = 0;
+    const bool timed = s->timing && (g.n_lk > 0 || (skip & 8)) && s->ev_used + 2 <= s->ev.size();
+    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
+    OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
+    if (timed) {
+        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
+        s->ev_used += 2;
+    }
+    s->stream_n = f + 1;
+    return OFX_OK;
+}
+
+// Submit the next frame of the stream (one launch).  *completed_pair (may be NULL) receives the index p of the pair
+// (frame p-1 -> frame p, frames counted from 0) whose flow this launch writes, or -1 while the pipeline fills.
+extern "C" int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair)
+{
+    OFX_REQUIRE(s && d_gray1, "ofx_session_stream_submit: null argument");
+    if (s->stream_n < 0) {
+        ofx_set_error("ofx_session_stream_submit: call ofx_session_stream_begin first");
+        return OFX_E_STATE;
+    }
+    OFX_REQUIRE(s->stream_frames < 0, "ofx_session_stream_submit: the stream is being drained");
+    int dummy = -1;
+    return stream_tick(s, d_gray1, pitch, stream, completed_pair ? completed_pair : &dummy);
+}
+
+// Run one more tick without a new frame; call until it reports -2 in *completed_pair (pipeline empty).  Two ticks
+// drain a full pipeline.
+extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair)
+{
+    OFX_REQUIRE(s && completed_pair, "ofx_session_stream_drain: null argument");
+    if (s->stream_n < 0) {
+        ofx_set_error("ofx_session_stream_drain: not streaming");
+        return OFX_E_STATE;
+    }
+    if (s->stream_frames < 0) s->stream_frames = s->stream_n; // number of frames the stream received
+    if (s->stream_n >= s->stream_frames + 2) {
+        *completed_pair = -2;
+        s->stream_n = -1;
+        s->stream_frames = -1;
+        return OFX_OK;
+    }
+    return stream_tick(s, nullptr, 0, stream, completed_pair);
 }
 
 // gpu::calc_opt_flow (OptFlowGpu.cuh:33, OptFlowGpu.cu:1909-1979) with host pointers: upload both images and the

@@ -1,0 +1,237 @@
+// Device side of the staging kernels of a frame pair: pyramid (level by level and fused), global shift.  Shared by the
+// stand-alone kernels in pyramid.hip and by the pipelined stream kernel in lk_level.hip.
+#pragma once
+
+#include "ofx_internal.h"
+
+namespace ofx_dev {
+
+// ---------------------------------------------------------------------------------------------------------------
+// 2x decimating 3x3 Gaussian on a 1ch plane (OptFlowGpu.cu:1198-1232 / OptFlowCPU.cpp:112-148 with
+// GAUS_KERNEL_3x3 = [1 2 1]^T [1 2 1] / 16, kernels.cpp:61-64).  The reference accumulates in float and truncates;
+// with power-of-two weights and u8 inputs every partial sum is exact, so integer (sum >> 4) is bit-identical.
+// Source taps at column/row -1 are outside the image and skipped; taps 2x+1 <= 2w-1 are always inside.
+// A lane produces 4 destination pixels from source columns 8c-1 .. 8c+7.
+struct DownArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    int src_pitch, src_row0, src_row_end; // source buffer holds source rows [src_row0, src_row_end)
+    int dw, dh, dst_pitch, dst_row0;      // destination level geometry
+    int out_y0, out_y1;
+};
+
+// 4 destination pixels (x0 multiple of 4, row y) from source columns 2*x0-1 .. 2*x0+7, rows 2y-1 .. 2y+1.
+// Source rows outside [row_lo,row_hi) and columns outside [0,sw) contribute nothing; destination columns >= dw give 0.
+__device__ __forceinline__ uint32_t down4(const uint8_t *src, int src_pitch, int src_row0, int row_lo, int row_hi, int sw, int dw,
+                                          int x0, int y)
+{
+    int col[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // vertical [1 2 1] of source columns 2*x0-1 .. 2*x0+7
+    const int sx = 2 * x0;                     // multiple of 8
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int sy = 2 * y - 1 + p;
+        if (sy < row_lo || sy >= row_hi) continue;
+        const int wgt = (p == 1) ? 2 : 1;
+        const uint8_t *row = src + (size_t)(sy - src_row0) * (size_t)src_pitch;
+        uint32_t lo = 0, hi = 0;
+        // the source pitch is a multiple of 4 and >= sw, so a dword starting below sw stays inside the row pitch
+        if (sx < sw) lo = *reinterpret_cast<const uint32_t *>(row + sx);
+        if (sx + 4 < sw) hi = *reinterpret_cast<const uint32_t *>(row + sx + 4);
+        const int left = (sx > 0 && sx - 1 < sw) ? row[sx - 1] : 0;
+        col[0] += wgt * left;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int a = (lo >> (8 * k)) & 0xff, b = (hi >> (8 * k)) & 0xff;
+            col[1 + k] += wgt * ((sx + k < sw) ? a : 0);
+            col[5 + k] += wgt * ((sx + 4 + k < sw) ? b : 0);
+        }
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int v = (col[2 * k] + 2 * col[2 * k + 1] + col[2 * k + 2]) >> 4;
+        out |= (uint32_t)((x0 + k < dw) ? v : 0) << (8 * k); // pitch padding is written as zero
+    }
+    return out;
+}
+
+__device__ __forceinline__ void downsample_rows(const DownArgs &A, int c4 /* group of 4 destination columns */, int row)
+{
+    const int y = A.out_y0 + row;
+    const int x0 = 4 * c4;
+    if (x0 >= A.dw || y >= A.out_y1) return;
+    const int lo = A.src_row0 > 0 ? A.src_row0 : 0;
+    const uint32_t out = down4(A.src, A.src_pitch, A.src_row0, lo, A.src_row_end, 2 * A.dw, A.dw, x0, y);
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.dst_row0) * (size_t)A.dst_pitch + x0) = out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole pyramid in ONE launch.  A 256-thread workgroup takes a 64x64 tile of level 0 and produces its part of every
+// coarser level, keeping the intermediate levels in LDS.  The 3x3 stencil at stride 2 reads source columns 2x-1..2x+1,
+// so a tile only ever needs extra source data on its LEFT and TOP: level k+1 needs level k back to 2*X-1, i.e. a
+// one-sided halo of H_k = 2*H_{k+1}+1 pixels, H_0 = 2^n - 1 for n produced levels (15 px for a 5-level pyramid).
+// Pixels at negative coordinates are outside every level and read as 0 (skipped taps, OptFlowCPU.cpp:133).
+constexpr int kPyrTile = 64;
+constexpr int kPyrMaxProduced = 6; // levels 1..6 from level 0 in one launch (halo 63)
+
+struct PyrArgs {
+    const uint8_t *src;
+    uint8_t *dst[kPyrMaxProduced + 1]; // dst[k] = level k plane, k = 1..n
+    int pitch[kPyrMaxProduced + 1];    // pitch[0] = source pitch
+    int w[kPyrMaxProduced + 1], h[kPyrMaxProduced + 1];
+    int n;                             // produced levels
+    int stride[kPyrMaxProduced + 1];   // LDS row stride of level k's region
+    int lds_off[kPyrMaxProduced + 1];  // LDS byte offset of level k's region (levels alternate between two areas)
+    int dst0_pitch;                    // pitch of the optional level-0 copy dst[0]
+};
+
+constexpr int kPyrThreads = 256; // small workgroups: they must find room next to the LK waves of the previous pair
+
+// one workgroup (kPyrThreads threads, all of them must call this) = one level-0 tile (bx, by)
+__device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, int tid, uint8_t *lds)
+{
+    const int X0 = bx * kPyrTile, Y0 = by * kPyrTile;
+    const int H0 = (1 << A.n) - 1;
+
+    // optional: keep a copy of the level-0 tile next to the levels built from it (the stream pipeline reads the
+    // caller's frame only in the launch that receives it)
+    if (A.dst[0] != nullptr) {
+        constexpr int dw_per_row = kPyrTile / 4;
+        for (int i = tid; i < dw_per_row * kPyrTile; i += kPyrThreads) {
+            const int y = Y0 + i / dw_per_row, x = X0 + 4 * (i % dw_per_row);
+            if (y < A.h[0] && x < A.w[0]) {
+                uint32_t d = *reinterpret_cast<const uint32_t *>(A.src + (size_t)y * (size_t)A.pitch[0] + x);
+                if (x + 3 >= A.w[0]) d &= 0xffffffffu >> (8 * (x + 4 - A.w[0])); // padding bytes stay zero
+                *reinterpret_cast<uint32_t *>(A.dst[0] + (size_t)y * (size_t)A.dst0_pitch + x) = d;
+            }
+        }
+    }
+
+    for (int k = 0; k < A.n; ++k) {
+        // level k region origin O_k = X_k - H_k (size T_k + H_k); O_k = 2*O_{k+1} - 1, so the taps 2x-1..2x+1 of the
+        // level-(k+1) pixel at region column rx are the level-k region columns 2*rx .. 2*rx+2
+        const int Hn = H0 >> (k + 1), Tn = kPyrTile >> (k + 1), Xn = X0 >> (k + 1), Yn = Y0 >> (k + 1);
+        const uint8_t *srcr = lds + A.lds_off[k];
+        uint8_t *dstr = lds + A.lds_off[k + 1];
+        const int ss = A.stride[k], ds = A.stride[k + 1];
+        const int rn = Tn + Hn;
+        // a thread produces 4 horizontally adjacent pixels whose global x is a multiple of 4 (dword store of the tile part)
+        const int hq = (Hn + 3) & ~3, groups = (Tn + hq + 3) / 4;
+        for (int i = tid; i < groups * rn; i += kPyrThreads) {
+            const int ry = i / groups, g = i % groups;
+            const int y = Yn - Hn + ry, xb = Xn - hq + 4 * g; // global coordinates at level k+1
+            uint32_t packed = 0;
+            if (k == 0) {
+                // level 1 comes straight from HBM with aligned dword reads (the bulk of the work: no LDS staging of level 0)
+                if (y >= 0 && y < A.h[1] && xb >= 0 && xb < A.w[1])
+                    packed = down4(A.src, A.pitch[0], 0, 0, A.h[0], A.w[0], A.w[1], xb, y);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rx = xb + q - (Xn - Hn);
+                    if (rx >= 0 && rx < rn) dstr[ry * ds + rx] = (uint8_t)(packed >> (8 * q));
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x = xb + q, rx = x - (Xn - Hn);
+                    int v = 0;
+                    if (rx >= 0 && rx < rn) {
+                        if (x >= 0 && y >= 0 && x < A.w[k + 1] && y < A.h[k + 1]) {
+                            const uint8_t *p = srcr + (2 * ry) * ss + 2 * rx;
+                            const int c0 = p[0] + 2 * p[ss] + p[2 * ss];
+                            const int c1 = p[1] + 2 * p[ss + 1] + p[2 * ss + 1];
+                            const int c2 = p[2] + 2 * p[ss + 2] + p[2 * ss + 2];
+                            v = (c0 + 2 * c1 + c2) >> 4;
+                        }
+                        dstr[ry * ds + rx] = (uint8_t)v;
+                    }
+                    packed |= (uint32_t)v << (8 * q);
+                }
+            }
+            // the tile's own part (not the halo) goes to HBM
+            if (ry >= Hn && y < A.h[k + 1] && xb >= Xn && xb < A.w[k + 1]) {
+                uint8_t *row = A.dst[k + 1] + (size_t)y * (size_t)A.pitch[k + 1];
+                if (xb + 3 < Xn + Tn && xb + 3 < A.w[k + 1]) {
+                    *reinterpret_cast<uint32_t *>(row + xb) = packed;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (xb + q < Xn + Tn && xb + q < A.w[k + 1]) row[xb + q] = (uint8_t)(packed >> (8 * q));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// cpu::shift_back_pyramid on channel 0 (OptFlowCPU.cpp:247, :268-279), destination zero-initialised:
+//   target = ((int)(x+u), (int)(y+v)) with float add and truncation toward zero; inside the image -> copy;
+//   outside (or non-finite) -> the byte the leading memcpy of w*h bytes left there: the pixel's own value when
+//   3*(y*w+x) < w*h, else 0.
+struct ShiftArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    const float *uv;
+    int w, h, pitch, row0, row_end, out_y0, out_y1, blocks_x;
+};
+
+struct ShiftTable {
+    ShiftArgs lv[OFX_MAX_LEVELS];
+    int first_block[OFX_MAX_LEVELS + 1];
+    int n;
+};
+
+// one 256-thread block of the multi-level shift
+__device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int tid)
+{
+    if (blk >= T.first_block[T.n]) return;
+    int level = 0;
+    while (level + 1 < T.n && blk >= T.first_block[level + 1]) ++level;
+    const ShiftArgs &A = T.lv[level];
+    const int block = blk - T.first_block[level];
+    const int bx = block % A.blocks_x, by = block / A.blocks_x;
+    const int x0 = 4 * (bx * 256 + tid);
+    const int y = A.out_y0 + by;
+    if (x0 >= A.pitch || y >= A.out_y1) return;
+    const float u = A.uv[0], v = A.uv[1];
+    const float ty = (float)y + v;
+    const bool yin = ty > -1.0f && ty < (float)A.h;
+    const int ny = yin ? (int)ty : 0;
+    const bool yhave = ny >= A.row0 && ny < A.row_end;
+    const uint8_t *srow = A.src + (size_t)((yhave ? ny : A.row0) - A.row0) * (size_t)A.pitch;
+    const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
+    const long long third = (long long)A.w * (long long)A.h;
+    // target columns of this lane's 4 pixels (the column map does not depend on the row)
+    int nx[4];
+    bool xin[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tx = (float)(x0 + k) + u;
+        xin[k] = (x0 + k) < A.w && tx > -1.0f && tx < (float)A.w;
+        nx[k] = xin[k] ? (int)tx : 0;
+    }
+    uint32_t out;
+    if (yin && yhave && xin[0] && xin[1] && xin[2] && xin[3] && nx[1] == nx[0] + 1 && nx[2] == nx[0] + 2 && nx[3] == nx[0] + 3) {
+        // common case: four consecutive in-image targets -> one (generally unaligned) dword instead of four byte
+        // gathers; byte gathers cost a full address cycle per lane and made this kernel TA-bound
+        __builtin_memcpy(&out, srow + nx[0], 4);
+    } else {
+        out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int x = x0 + k;
+            int val = 0;
+            if (x < A.w) {
+                if (yin && yhave && xin[k]) {
+                    val = srow[nx[k]];
+                } else {
+                    val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
+                }
+            }
+            out |= (uint32_t)val << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+}
+
+} // namespace ofx_dev

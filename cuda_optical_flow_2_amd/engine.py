@@ -119,6 +119,41 @@ class Session:
     def swap(self):
         check(self.L.ofx_session_swap(self._h), "swap")
 
+    # ---- pipelined pair: staging on the session's aux stream under the previous pair's LK launch
+    def submit_device(self, t, stream=None):
+        assert t.is_cuda and t.dtype.itemsize == 1 and tuple(t.shape) == (self.height, self.width)
+        check(self.L.ofx_session_submit_device(self._h, t.data_ptr(), int(t.stride(0)), _stream_ptr(stream)), "submit_device")
+
+    def stage_frame(self, t, aux=None):
+        check(self.L.ofx_session_stage_frame(self._h, t.data_ptr(), int(t.stride(0)), aux), "stage_frame")
+
+    def stage_shift(self, aux=None):
+        check(self.L.ofx_session_stage_shift(self._h, aux), "stage_shift")
+
+    def solve_staged(self, stream=None):
+        check(self.L.ofx_session_solve_staged(self._h, _stream_ptr(stream)), "solve_staged")
+
+    def aux_stream_ptr(self) -> int:
+        p = _vp()
+        check(self.L.ofx_session_aux_stream(self._h, C.byref(p)), "aux_stream")
+        return p.value
+
+    # ---- stream pipeline: one launch per frame, flow of pair p ready after frame p+3
+    def stream_begin(self):
+        check(self.L.ofx_session_stream_begin(self._h), "stream_begin")
+
+    def stream_submit(self, t, stream=None) -> int:
+        assert t.is_cuda and t.dtype.itemsize == 1 and tuple(t.shape) == (self.height, self.width)
+        done = C.c_int(-1)
+        check(self.L.ofx_session_stream_submit(self._h, t.data_ptr(), int(t.stride(0)), _stream_ptr(stream), C.byref(done)),
+              "stream_submit")
+        return done.value
+
+    def stream_drain(self, stream=None) -> int:
+        done = C.c_int(-1)
+        check(self.L.ofx_session_stream_drain(self._h, _stream_ptr(stream), C.byref(done)), "stream_drain")
+        return done.value
+
     def push_frame_host(self, gray1: np.ndarray, stream=None):
         """Load a frame, build its pyramid and make it the previous frame (priming step of main.cu:203-209)."""
         self.set_frame_host(gray1, stream)

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libofx_hip.so")
+LIB_PATH = os.path.join(PKG, os.environ.get("OFX_LIB", "libofx_hip.so"))  # OFX_LIB: A/B an alternative build
 
 OFX_MAX_LEVELS = 12
 MODE_COMPAT_CPU = 0
@@ -54,6 +54,7 @@ _SIGS = {
     "ofx_shift_levels": [_vp, _i, _vp],
     "ofx_lk_level_sums": [_vp, _vp, _gp, _i, _i, _vp, _i, _vp],
     "ofx_downsample_1ch": [_vp, _i, _i, _i, _vp, _gp, _vp],
+    "ofx_pyramid_1ch": [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _i, _vp],
     "ofx_shift_vector": [C.POINTER(_vp), _i, _i, _vp, _vp],
     "ofx_shift_1ch": [_vp, _vp, _gp, _vp, _vp],
     "ofx_compose_flow": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp],
@@ -84,6 +85,15 @@ _SIGS = {
     "ofx_session_compute_uv": [_vp, _i, _vp],
     "ofx_session_run_level": [_vp, _i, _vp],
     "ofx_session_swap": [_vp],
+    "ofx_session_stream_begin": [_vp],
+    "ofx_session_stream_submit": [_vp, _vp, _i, _vp, C.POINTER(_i)],
+    "ofx_session_stream_drain": [_vp, _vp, C.POINTER(_i)],
+    "ofx_stream_launch": [_vp, _i, _i, _vp],
+    "ofx_session_submit_device": [_vp, _vp, _i, _vp],
+    "ofx_session_stage_frame": [_vp, _vp, _i, _vp],
+    "ofx_session_stage_shift": [_vp, _vp],
+    "ofx_session_solve_staged": [_vp, _vp],
+    "ofx_session_aux_stream": [_vp, C.POINTER(_vp)],
     "ofx_session_plane": [_vp, _i, _i, C.POINTER(_vp), _gp],
     "ofx_session_flow": [_vp, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "ofx_session_shift_uv": [_vp, _i, C.POINTER(_vp)],

@@ -93,6 +93,29 @@ class HipBackend:
     def load_frame(self, frame):
         self.session.set_frame_device(frame)
 
+    def pipelined_step(self, frame, rank: int, world: int):
+        """One pair with the staging half (frame load, pyramid, corner flows, broadcast, shifts) on the session's
+        auxiliary stream, so that it runs underneath the previous pair's LK launch; the solve half goes on the current
+        stream.  Same results as load_frame/build_pyramid/corner_flows/broadcast/run_levels/swap."""
+        import torch
+        import torch.distributed as dist
+
+        if not hasattr(self, "_aux"):
+            self._aux_ptr = self.session.aux_stream_ptr()
+            self._aux = torch.cuda.ExternalStream(self._aux_ptr)
+        s = self.session
+        with torch.cuda.stream(self._aux):
+            s.stage_frame(frame, self._aux_ptr)
+            if rank == 0:
+                s.corner_flows(self._aux)
+            if world > 1:
+                if rank == 0:
+                    self.uv_stage.copy_(self.uv_all)
+                dist.broadcast(self.uv_stage, src=0)   # issued against the current (= aux) stream
+                self.uv_all.copy_(self.uv_stage)
+            s.stage_shift(self._aux_ptr)
+        s.solve_staged()
+
     def build_pyramid(self):
         self.session.build_pyramid()
 
@@ -112,9 +135,9 @@ class HipBackend:
 class ShardedFlow:
     """One frame pair per step(), row-sharded over the ranks of the default process group."""
 
-    def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None):
+    def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True):
         self.plan = ShardPlan(width, height, levels, window, rank, world, margin)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.pipelined = rank, world, pipelined
         self.backend = backend if backend is not None else HipBackend(self.plan, mode, device)
         self.session = getattr(self.backend, "session", None)
 
@@ -130,6 +153,9 @@ class ShardedFlow:
         import torch.distributed as dist
 
         b = self.backend
+        if self.pipelined and not check_margin and hasattr(b, "pipelined_step"):
+            b.pipelined_step(frame, self.rank, self.world)
+            return
         b.load_frame(frame)
         b.build_pyramid()
         if self.rank == 0:

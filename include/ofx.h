@@ -76,7 +76,7 @@ typedef struct ofx_geom {
  * windowed sums of products and the 2x2 solve in one kernel.
  * Replaces the device work of gpu::calc_opt_flow (OptFlowGpu.cu:1930-1964) /
  * cpu::calc_optical_flow steps 1-3 (OptFlowCPU.cpp:329-384) for one level.
- * d_next must already be shifted (ofx_shift_1ch) when level != top.
+ * d_next must already be shifted (ofx_shift_1ch) when level != top (or use ofx_lk_levels with d_uv).
  * d_flow receives rows [out_y0,out_y1) at row offset (y - flow_row0).
  * window: odd, 3..23 (lk_float) / 3..25 (compat_cpu). */
 int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g, int window, int mode,
@@ -86,12 +86,46 @@ int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const ofx_geom *g
  * ofx_corner_flows).  Descriptors are processed in the order given; coarse levels first is the useful order. */
 typedef struct ofx_lk_desc {
     const uint8_t *d_prev;
-    const uint8_t *d_next; /* already shifted below the top level */
+    const uint8_t *d_next;
     ofx_geom geom;
     float *d_flow;
     int flow_row0;
+    /* NULL: d_next is used as it is (top level, or already shifted with ofx_shift_1ch).  Non-NULL: 2 floats on the
+     * device; the kernel reads d_next THROUGH the reference's global shift by that vector (cpu::shift_back_pyramid,
+     * OptFlowCPU.cpp:241-282, fused into the row loads) -- same bits as shifting first, without the extra pass. */
+    const float *d_uv;
 } ofx_lk_desc;
 int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
+
+/* descriptor of one level's shift (ofx_shift_levels, ofx_stream_launch) */
+typedef struct ofx_shift_desc {
+    const uint8_t *d_src;
+    uint8_t *d_dst;
+    ofx_geom geom;
+    const float *d_uv;
+} ofx_shift_desc;
+
+/* One tick of the frame-stream pipeline in ONE launch: pyramid of the newest frame | corner flows of the pair before |
+ * shifts of the pair before that | fused LK of the pair before that, as disjoint block ranges of one grid.  Every stage
+ * only reads what earlier launches wrote, so the stages need no synchronisation; a stage is skipped when its count is 0.
+ * ofx_session_stream_submit drives this; it is exposed for callers that manage their own buffers. */
+typedef struct ofx_stream_stages {
+    /* pyramid: levels 1..pyr_levels-1 from d_frame, plus a copy of level 0 into d_levels[0] (pyr_levels = 0: none) */
+    const uint8_t *d_frame;
+    int frame_pitch, w, h, pyr_levels;
+    uint8_t *d_levels[OFX_MAX_LEVELS];
+    int pitches[OFX_MAX_LEVELS];
+    /* corner flows: descriptors as for ofx_corner_flows (corner_levels = 0: none) */
+    ofx_lk_desc corner[OFX_MAX_LEVELS];
+    int corner_levels;
+    float *d_uv;
+    /* shifts and fused LK */
+    ofx_shift_desc shift[OFX_MAX_LEVELS];
+    int n_shift;
+    ofx_lk_desc lk[OFX_MAX_LEVELS];
+    int n_lk;
+} ofx_stream_stages;
+int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
 
 /* Same level, but stopping before the solve: writes the five window sums
  * (Sxx, Syy, Sxy, Sxt, Syt) as int32 planes of w ints per row.  Test/inspection
@@ -108,6 +142,11 @@ int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, const ofx_ge
 int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_row0, int src_rows,
                        uint8_t *d_dst, const ofx_geom *dst, void *stream);
 
+/* All levels of a grey pyramid from level 0 in ONE launch (same arithmetic as ofx_downsample_1ch level by level;
+ * whole, unsharded levels only).  d_levels[k] / pitches[k] for k = 1..levels-1 (index 0 unused). */
+int ofx_pyramid_1ch(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches,
+                    int levels, void *stream);
+
 /* Translation the reference applies to `next` below the top level:
  * (u,v) = sum_{k=top..level+1} 2^(k-level) * flow_k[pixel 0]  in float, coarsest
  * first (OptFlowCPU.cpp:255-266, where `i * (1 >> offset)` is always 0).
@@ -123,13 +162,7 @@ int ofx_shift_vector(const float *const *d_flow_levels, int level, int max_level
  * Descriptors: index k = pyramid level k, d_next = the UNSHIFTED next plane, geom.row0 must be 0. */
 int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, void *stream);
 
-/* Several ofx_shift_1ch calls in one launch. */
-typedef struct ofx_shift_desc {
-    const uint8_t *d_src;
-    uint8_t *d_dst;
-    ofx_geom geom;
-    const float *d_uv;
-} ofx_shift_desc;
+/* Several ofx_shift_1ch calls in one launch (ofx_shift_desc is declared above). */
 int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream);
 
 /* dst(x,y) = src((int)(x+u), (int)(y+v)) when that lands inside the image,
@@ -231,6 +264,26 @@ int ofx_session_run_flow_sequential(ofx_session *s, void *stream);
 int ofx_session_compute_uv(ofx_session *s, int level, void *stream);
 /* Shift (below the top level) + fused LK of one level, own rows, using the uv slot as it stands. */
 int ofx_session_run_level(ofx_session *s, int level, void *stream);
+/* Pipelined pair (throughput path): the staging half of a pair -- frame load, pyramid, corner flows, shifts -- runs on
+ * a session-owned auxiliary stream underneath the previous pair's LK launch; the solve half runs on `stream`.
+ * ofx_session_submit_device does a whole pair and leaves the new frame as the previous one; results are bit-identical
+ * to set_frame_device + build_pyramid + run_flow + swap.  d_gray1 must be complete in HBM at the call.
+ * A sharded driver issues the halves itself: stage_frame; corner_flows (rank holding row 0) and the broadcast of the
+ * shift vectors on the aux stream (ofx_session_aux_stream); stage_shift; solve_staged. */
+int ofx_session_submit_device(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream);
+int ofx_session_stage_frame(ofx_session *s, const uint8_t *d_gray1, int pitch, void *aux_stream);
+int ofx_session_stage_shift(ofx_session *s, void *aux_stream);
+int ofx_session_solve_staged(ofx_session *s, void *stream);
+int ofx_session_aux_stream(ofx_session *s, void **stream);
+/* Stream pipeline (highest throughput, single GPU): every submitted frame costs ONE launch (ofx_stream_launch) in which
+ * the pyramid of that frame, the corner flows of the pair before and the fused LK (shift included) of the pair before
+ * that run side by side.  The flow of pair p (frame p-1 -> frame p, frames counted from 0) is written by the launch of
+ * frame p+2; *completed_pair reports which pair a call produced (-1 while the pipeline fills).  After the
+ * last frame call ofx_session_stream_drain until it reports -2.  Results are bit-identical to the pair-at-a-time paths.
+ * The frame buffer must stay valid until the launch that received it has finished. */
+int ofx_session_stream_begin(ofx_session *s);
+int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair);
+int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair);
 /* prev <- next (main.cu:270-272). */
 int ofx_session_swap(ofx_session *s);
 /* Device pointers / geometry of the session's buffers. which: 0 = prev, 1 = next, 2 = shifted scratch. */

@@ -262,6 +262,80 @@ def test_sharded_sessions_on_one_device(eng, mode):
         r.session.close()
 
 
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_pipelined_submit_equals_plain_sequence(eng, mode):
+    """submit_device (staging on the aux stream under the previous LK launch, three rotating image sets) must give, for
+    EVERY pair of a back-to-back stream, the bits of set_frame/build_pyramid/run_flow/swap.  Flow snapshots are taken with
+    stream-ordered device copies so that the pairs really are in flight together."""
+    import torch
+
+    w, h, L, win, nf = 512, 384, 4, 9, 7
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.7 * i, -0.9 * i, seed=21)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, mode)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = []
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want.append([plain.flow_host(k) for k in range(L)])
+        plain.swap()
+    plain.close()
+
+    piped = eng.Session(w, h, L, win, mode)
+    piped.set_frame_device(frames[0]); piped.build_pyramid(); piped.swap()
+    torch.cuda.synchronize()
+    snaps = []
+    for i in range(1, nf):
+        piped.submit_device(frames[i])
+        snaps.append([piped.flow(k)[0].clone() for k in range(L)])   # ordered after LK(i) on the current stream
+    torch.cuda.synchronize()
+    for i, (got, ref) in enumerate(zip(snaps, want)):
+        for k in range(L):
+            assert_same(got[k].cpu().numpy(), ref[k], f"{mode} pair {i + 1} level {k}")
+    piped.close()
+
+
+@pytest.mark.parametrize("cfg", [(512, 384, 4, 9, "lk_float"), (512, 384, 4, 9, "compat_cpu"), (320, 200, 3, 15, "lk_float"), (64, 32, 2, 3, "lk_float")])
+def test_stream_pipeline_equals_plain_sequence(eng, cfg):
+    """The one-launch-per-frame stream pipeline (pyramid | corner | shift | LK of four consecutive pairs side by side in one
+    grid) must reproduce, pair by pair, the bits of the plain sequence; pair p's flow appears with frame p+2."""
+    import torch
+
+    w, h, L, win, mode = cfg
+    nf = 9
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=31)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, mode)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+
+    s = eng.Session(w, h, L, win, mode)
+    s.stream_begin()
+    got = {}
+    for i in range(nf):
+        done = s.stream_submit(frames[i])
+        assert done == (i - 2 if i - 2 >= 1 else -1)
+        if done >= 1:
+            got[done] = [s.flow(k)[0].clone() for k in range(L)]   # stream-ordered snapshot, launches stay in flight
+    while True:
+        done = s.stream_drain()
+        if done == -2:
+            break
+        if done >= 1:
+            got[done] = [s.flow(k)[0].clone() for k in range(L)]
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(1, nf))
+    for p in range(1, nf):
+        for k in range(L):
+            assert_same(got[p][k].cpu().numpy(), want[p][k], f"{mode} pair {p} level {k}")
+    s.close()
+
+
 def test_session_rejects_bad_configs(eng):
     from cuda_optical_flow_2_amd.lib import OfxError
 

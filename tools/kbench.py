@@ -13,6 +13,7 @@ for nm in names:
     s.push_frame_host(p)
     s.set_frame_host(n); s.build_pyramid(); s.run_flow(); torch.cuda.synchronize()
     tn = torch.from_numpy(n).cuda()
+    print("   shift vectors (u,v) per level:", [tuple(round(float(x), 3) for x in s.uv(k).cpu().tolist()) for k in range(L - 1)])
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     def timeit(fn, reps=30):
         best = 1e9
