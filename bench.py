@@ -158,6 +158,9 @@ def main():
         own_px = sum((w >> k) * ((h >> k) if driver is None else (driver.plan.own[k][1] - driver.plan.own[k][0]))
                      for k in range(levels))
         lk_bytes = LK_BYTES_PER_PX * own_px
+        if world == 1 and args.path == "stream":
+            # the stream launch also builds the next frame's pyramid: + 5 B per destination pixel of levels 1..
+            lk_bytes += 5 * sum((w >> k) * (h >> k) for k in range(1, levels))
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -184,7 +187,8 @@ def main():
                 "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
             },
             "roofline": {
-                "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels + pyramid + corner + shifts; bytes counted: LK only)"
+                "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels for pair j-2 | corner flows of pair j-1 | pyramid of "
+                            "frame j; bytes = 10 B/px LK + 5 B/px pyramid)"
                            if world == 1 and args.path == "stream" else
                            "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -33,6 +33,9 @@ struct ofx_session {
     hipEvent_t ev_set_done[3] = {nullptr, nullptr, nullptr}; // last LK launch that read img[i] as `prev` finished
     bool set_busy[3] = {false, false, false};
     bool staged = false;
+    int uv_slot = 0; // shift-vector slot of the pair in progress; alternates per pair so that the staging of the next
+                     // pair (aux stream) never overwrites vectors the running LK launch still reads
+    float *uv_cur() { return uv + (size_t)uv_slot * 2 * OFX_MAX_LEVELS; }
     long stream_n = -1;      // ticks of the stream pipeline so far (-1: not streaming)
     long stream_frames = -1; // total frames, known once draining starts (-1: still receiving)
     // index of the newest frame whose pyramid exists once tick f has been issued
@@ -260,7 +263,7 @@ extern "C" int ofx_session_compute_uv(ofx_session *s, int level, void *stream)
     if (level == s->p.levels - 1) return OFX_OK; // top level is not shifted (OptFlowCPU.cpp:321)
     const float *lv[OFX_MAX_LEVELS] = {};
     for (int k = 0; k < s->p.levels; ++k) lv[k] = s->flow[k];
-    return ofx_shift_vector(lv, level, s->p.levels, s->uv + 2 * level, stream);
+    return ofx_shift_vector(lv, level, s->p.levels, s->uv_cur() + 2 * level, stream);
 }
 
 extern "C" int ofx_session_run_level(ofx_session *s, int level, void *stream)
@@ -279,7 +282,7 @@ extern "C" int ofx_session_run_level(ofx_session *s, int level, void *stream)
         if (y0 < s->buf0[level]) y0 = s->buf0[level];
         if (y1 > s->buf1[level]) y1 = s->buf1[level];
         const ofx_geom gs = level_geom(s, level, y0, y1);
-        OFX_TRY(ofx_shift_1ch(s->plane[1][level], s->plane[2][level], &gs, s->uv + 2 * level, stream));
+        OFX_TRY(ofx_shift_1ch(s->plane[1][level], s->plane[2][level], &gs, s->uv_cur() + 2 * level, stream));
         next = s->plane[2][level];
     }
     const ofx_geom g = level_geom(s, level, s->own0[level], s->own1[level]);
@@ -338,7 +341,7 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
     ofx_lk_desc d[OFX_MAX_LEVELS];
     for (int k = 0; k < s->p.levels; ++k)
         d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr};
-    return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv, stream);
+    return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv_cur(), stream);
 }
 
 // Every level's fused LK in one launch, using the uv slots as they stand; below the top level the kernel reads `next`
@@ -368,7 +371,7 @@ extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
         ofx_set_error("ofx_session_run_levels: need a previous and a next frame");
         return OFX_E_STATE;
     }
-    return lk_all_levels(s, s->uv, stream);
+    return lk_all_levels(s, s->uv_cur(), stream);
 }
 
 extern "C" int ofx_session_run_flow(ofx_session *s, void *stream)
@@ -395,6 +398,7 @@ extern "C" int ofx_session_swap(ofx_session *s)
 {
     OFX_REQUIRE(s, "ofx_session_swap: null session");
     s->cur = (s->cur + 1) % 3;
+    s->uv_slot ^= 1;
     repoint(s);
     s->have_prev = s->have_next;
     s->have_next = false;
@@ -473,11 +477,7 @@ extern "C" int ofx_session_solve_staged(ofx_session *s, void *stream)
     }
     hipStream_t st = ofx_stream(stream);
     OFX_HIP(hipStreamWaitEvent(st, s->ev_ready, 0));
-    // the shift vectors of this pair are copied out of the shared slot on the solve stream's side: the next pair's
-    // corner kernel (aux stream) overwrites the slot while this LK launch may still be reading it
-    float *uv_pair = s->uv + 2 * OFX_MAX_LEVELS;
-    OFX_HIP(hipMemcpyAsync(uv_pair, s->uv, 2 * OFX_MAX_LEVELS * sizeof(float), hipMemcpyDeviceToDevice, st));
-    OFX_TRY(lk_all_levels(s, uv_pair, stream));
+    OFX_TRY(lk_all_levels(s, s->uv_cur(), stream));
     OFX_HIP(hipEventRecord(s->ev_set_done[s->cur], st));
     s->set_busy[s->cur] = true;
     return ofx_session_swap(s);
@@ -517,7 +517,7 @@ extern "C" int ofx_session_flow(ofx_session *s, int level, float **d_ptr, int *r
 extern "C" int ofx_session_shift_uv(ofx_session *s, int level, float **d_uv)
 {
     OFX_REQUIRE(s && d_uv && level >= 0 && level < s->p.levels, "ofx_session_shift_uv: bad arguments");
-    *d_uv = s->uv + 2 * level;
+    *d_uv = s->uv_cur() + 2 * level; // slot of the pair in progress (alternates per pair)
     return OFX_OK;
 }
 

@@ -184,6 +184,7 @@ class Session:
         return DeviceView(ptr.value, (rows.value, w, 2), "<f4").tensor(), r0.value
 
     def uv(self, level: int):
+        """Shift vector of `level` for the pair in progress (the slot alternates per pair: query after every swap)."""
         ptr = _vp()
         check(self.L.ofx_session_shift_uv(self._h, level, C.byref(ptr)), "session_shift_uv")
         return DeviceView(ptr.value, (2,), "<f4").tensor()

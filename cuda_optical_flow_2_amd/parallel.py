@@ -85,10 +85,20 @@ class HipBackend:
 
         self.plan = plan
         self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan)
-        # the session keeps 2 floats per level contiguously; a view over all of them is what gets broadcast
-        self.uv_all = engine.DeviceView(self.session.uv(0).data_ptr(), (2 * plan.levels,), "<f4").tensor()
+        self._views = {}
         # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
         self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
+
+    @property
+    def uv_all(self):
+        """View over the 2*levels shift-vector floats of the pair in progress (the session alternates two slots)."""
+        from . import engine
+
+        ptr = self.session.uv(0).data_ptr()
+        v = self._views.get(ptr)
+        if v is None:
+            v = self._views[ptr] = engine.DeviceView(ptr, (2 * self.plan.levels,), "<f4").tensor()
+        return v
 
     def load_frame(self, frame):
         self.session.set_frame_device(frame)

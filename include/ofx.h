@@ -289,6 +289,8 @@ int ofx_session_swap(ofx_session *s);
 /* Device pointers / geometry of the session's buffers. which: 0 = prev, 1 = next, 2 = shifted scratch. */
 int ofx_session_plane(ofx_session *s, int which, int level, uint8_t **d_ptr, ofx_geom *geom);
 int ofx_session_flow(ofx_session *s, int level, float **d_ptr, int *row0, int *rows);
+/* Shift vector slot of `level` for the pair IN PROGRESS (2 floats; levels are contiguous, 2 floats apart).  The session
+ * alternates between two slots per pair, so query it again after every ofx_session_swap / solve_staged. */
 int ofx_session_shift_uv(ofx_session *s, int level, float **d_uv);
 /* Copy one level's flow (the rows this session owns, tightly packed) to host, synchronising `stream`. */
 int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst, void *stream);

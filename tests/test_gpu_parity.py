@@ -269,7 +269,7 @@ def test_pipelined_submit_equals_plain_sequence(eng, mode):
     stream-ordered device copies so that the pairs really are in flight together."""
     import torch
 
-    w, h, L, win, nf = 512, 384, 4, 9, 7
+    w, h, L, win, nf = 1280, 720, 4, 9, 6   # large enough that an LK launch outlasts the next pair's staging
     frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.7 * i, -0.9 * i, seed=21)[1]).cuda() for i in range(nf)]
     plain = eng.Session(w, h, L, win, mode)
     plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
@@ -334,6 +334,30 @@ def test_stream_pipeline_equals_plain_sequence(eng, cfg):
         for k in range(L):
             assert_same(got[p][k].cpu().numpy(), want[p][k], f"{mode} pair {p} level {k}")
     s.close()
+
+
+def test_sharded_driver_single_rank_pipelined(eng):
+    """parallel.ShardedFlow with world = 1 drives the staged halves (stage_frame / corner_flows / stage_shift /
+    solve_staged on the session's aux stream) exactly as bench.py --gpus N does on every rank; the broadcast is the only
+    step a single rank skips."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardedFlow
+
+    w, h, L, win = 640, 480, 3, 7
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, 0.6 * i, seed=9)[1]).cuda() for i in range(5)]
+    plain = eng.Session(w, h, L, win, "lk_float")
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    drv = ShardedFlow(w, h, L, win, "lk_float", 0, 1)
+    drv.push_frame(frames[0])
+    for i in range(1, 5):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        drv.step(frames[i])
+        torch.cuda.synchronize()
+        for k in range(L):
+            assert_same(drv.gather_flow(k).cpu().numpy(), plain.flow_host(k), f"pair {i} level {k}")
+        plain.swap()
+    plain.close()
+    drv.session.close()
 
 
 def test_session_rejects_bad_configs(eng):
