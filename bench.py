@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
     ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
                     help="single-GPU execution path: stream pipeline (default), two-stream staged pairs, or the plain sequence")
+    ap.add_argument("--iters", type=int, default=1,
+                    help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -93,7 +95,9 @@ def main():
     d_frames = [torch.from_numpy(f).cuda() for f in frames]
 
     if world == 1:
-        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank)
+        if args.iters > 1:
+            args.path = "plain"
+        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters)
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
@@ -158,6 +162,9 @@ def main():
         own_px = sum((w >> k) * ((h >> k) if driver is None else (driver.plan.own[k][1] - driver.plan.own[k][0]))
                      for k in range(levels))
         lk_bytes = LK_BYTES_PER_PX * own_px
+        if args.iters > 1:
+            # timed span = shift + LK + (iters-1) x (warp + accumulating LK): shift 2 B/px, warp 1+8+1 B/px, LK + 8 B/px
+            lk_bytes += 2 * own_px + (args.iters - 1) * (10 + 18) * own_px
         if world == 1 and args.path == "stream":
             # the stream launch also builds the next frame's pyramid: + 5 B per destination pixel of levels 1..
             lk_bytes += 5 * sum((w >> k) * (h >> k) for k in range(1, levels))
@@ -182,8 +189,9 @@ def main():
             "dtype": "i32/f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters=1 (the only value the "
-                            f"reference defines), mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
+                "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
+                            f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
+                            f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
                 "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
             },
             "roofline": {

@@ -19,6 +19,7 @@ struct LkArgs {
     int w, h, pitch, row0, row_end; // buffer holds global rows [row0,row_end)
     int out_y0, out_y1, flow_row0;
     int strip_h, tiles_x;
+    int accumulate; // non-zero: flow += result (refinement iterations) instead of flow = result
 };
 
 // one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
@@ -476,6 +477,14 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
                     float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
+                    if (A.accumulate) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (cb + j < A.w) {
+                                uv[2 * j] = dst[2 * j] + uv[2 * j];
+                                uv[2 * j + 1] = dst[2 * j + 1] + uv[2 * j + 1];
+                            }
+                    }
                     if (cb + 3 < A.w) {
                         // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
                         float2 *d2 = reinterpret_cast<float2 *>(dst);

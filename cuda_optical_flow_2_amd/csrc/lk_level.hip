@@ -225,6 +225,7 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
         a.prev = d[i].d_prev;
         a.next = d[i].d_next;
         a.uv = d[i].d_uv;
+        a.accumulate = d[i].accumulate;
         a.flow = d[i].d_flow;
         a.sums = d_sums;
         // plane stride of the inspection output = rows from flow_row0 to out_y1
@@ -300,7 +301,7 @@ extern "C" int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const 
                             float *d_flow, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_flow && g, "ofx_lk_level: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0, nullptr};
+    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0, nullptr, 0};
     return lk_dispatch(&d, 1, window, mode, nullptr, stream);
 }
 
@@ -308,6 +309,6 @@ extern "C" int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, c
                                  int32_t *d_sums5, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_sums5 && g, "ofx_lk_level_sums: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0, nullptr};
+    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0, nullptr, 0};
     return lk_dispatch(&d, 1, window, mode, d_sums5, stream);
 }

@@ -23,6 +23,11 @@ __global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftTable T)
     shift_block(T, (int)blockIdx.x, (int)threadIdx.x);
 }
 
+__global__ __launch_bounds__(256) void warp_u8_kernel(const WarpTable T)
+{
+    warp_block(T, (int)blockIdx.x, (int)threadIdx.x);
+}
+
 // 3-channel variant, one thread per destination pixel (API-compat path only: gpu::gauss_pyramid on colour images)
 __global__ __launch_bounds__(256) void downsample_3ch_kernel(const uint8_t *src, uint8_t *dst, int dw, int dh)
 {
@@ -272,6 +277,34 @@ extern "C" int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geo
     OFX_REQUIRE(g != nullptr, "ofx_shift_1ch: geometry is null");
     ofx_shift_desc d{d_src, d_dst, *g, d_uv};
     return ofx_shift_levels(&d, 1, stream);
+}
+
+extern "C" int ofx_warp_levels(const ofx_warp_desc *levels, int n, void *stream)
+{
+    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_warp_levels: bad descriptor count %d", n);
+    WarpTable t{};
+    int blocks = 0, m = 0;
+    for (int i = 0; i < n; ++i) {
+        const ofx_geom *g = &levels[i].geom;
+        OFX_TRY(ofx_check_geom(g, "ofx_warp_levels"));
+        OFX_REQUIRE(levels[i].d_src && levels[i].d_dst && levels[i].d_flow, "ofx_warp_levels: null pointer");
+        OFX_REQUIRE(levels[i].d_src != levels[i].d_dst, "ofx_warp_levels: in-place warp is not supported");
+        OFX_REQUIRE(g->row0 == 0 && g->rows == g->h, "ofx_warp_levels: whole levels only (the warp may read any row)");
+        OFX_REQUIRE(levels[i].flow_row0 <= g->out_y0, "ofx_warp_levels: flow_row0 > out_y0");
+        if (g->out_y1 <= g->out_y0) continue;
+        const int bx = ofx_div_up(g->pitch / 4, 256);
+        t.lv[m] = WarpArgs{levels[i].d_src, levels[i].d_dst, levels[i].d_flow, levels[i].scale, g->w, g->h, g->pitch, g->row0,
+                           g->out_y0, g->out_y1, levels[i].flow_row0, bx};
+        t.first_block[m] = blocks;
+        blocks += bx * (g->out_y1 - g->out_y0);
+        ++m;
+    }
+    if (m == 0) return OFX_OK;
+    t.n = m;
+    t.first_block[m] = blocks;
+    hipLaunchKernelGGL(warp_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, ofx_stream(stream), t);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
 }
 
 extern "C" int ofx_compose_flow(const float *const *d_flow_levels, int w, int h, int levels, int level, float *d_dst,

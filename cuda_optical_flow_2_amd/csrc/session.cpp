@@ -82,6 +82,9 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(p->levels >= 1 && p->levels <= OFX_MAX_LEVELS, "ofx_session_create: levels %d out of range", p->levels);
     OFX_REQUIRE(p->window >= 3 && (p->window & 1), "ofx_session_create: window must be odd and >= 3");
     OFX_REQUIRE(p->mode == OFX_MODE_COMPAT_CPU || p->mode == OFX_MODE_LK_FLOAT, "ofx_session_create: bad mode %d", p->mode);
+    OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
+    OFX_REQUIRE(p->iters <= 1 || (p->mode == OFX_MODE_LK_FLOAT && !p->sharded),
+                "ofx_session_create: refinement iterations need mode lk_float and an unsharded session");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
                 "ofx_session_create: %d levels is too many for %dx%d", p->levels, p->width, p->height);
     for (int k = 0; k + 1 < p->levels; ++k)
@@ -350,13 +353,40 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
 {
     const int L = s->p.levels;
     ofx_lk_desc lk[OFX_MAX_LEVELS];
-    int nl = 0;
-    for (int k = L - 1; k >= 0; --k) // coarse levels first: their few waves start at once and finish early
-        lk[nl++] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k],
-                               k == L - 1 ? nullptr : uv + 2 * k};
     const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
     if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
-    OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+    if (s->p.iters <= 1) {
+        int nl = 0;
+        for (int k = L - 1; k >= 0; --k) // coarse levels first: their few waves start at once and finish early
+            lk[nl++] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k],
+                                   k == L - 1 ? nullptr : uv + 2 * k, 0};
+        OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+    } else {
+        // Extension (DESIGN.md "lk_iter"): iteration 1 is the reference level; every further iteration warps
+        // the shifted next image by the flow so far (bilinear, rounded to u8) and adds the flow of (prev, warped).
+        // sh[0] holds the globally shifted next image (the warp source), sh[1] the warped image.
+        ofx_shift_desc sd[OFX_MAX_LEVELS];
+        int ns = 0;
+        for (int k = L - 2; k >= 0; --k)
+            sd[ns++] = ofx_shift_desc{s->plane[1][k], s->sh[0][k], level_geom(s, k, 0, s->h[k]), uv + 2 * k};
+        if (ns) OFX_TRY(ofx_shift_levels(sd, ns, stream));
+        auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
+        int nl = 0;
+        for (int k = L - 1; k >= 0; --k)
+            lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0};
+        OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+        for (int it = 1; it < s->p.iters; ++it) {
+            ofx_warp_desc wd[OFX_MAX_LEVELS];
+            nl = 0;
+            for (int k = L - 1; k >= 0; --k) {
+                wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE};
+                lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1};
+                ++nl;
+            }
+            OFX_TRY(ofx_warp_levels(wd, nl, stream));
+            OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+        }
+    }
     if (timed) {
         OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
         s->ev_used += 2;
@@ -541,6 +571,7 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
     OFX_REQUIRE(s, "ofx_session_stream_begin: null session");
     OFX_REQUIRE(!s->p.sharded, "ofx_session_stream_begin: the stream pipeline runs whole frames; shard with the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
+    OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
     s->stream_n = 0;
     s->have_prev = s->have_next = s->staged = false;
     return OFX_OK;

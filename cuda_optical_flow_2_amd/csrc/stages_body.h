@@ -234,4 +234,64 @@ __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int ti
     *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Extension (no reference twin; DESIGN.md "lk_iter"): dst(x,y) = round_u8(bilinear(src, x + s*u, y + s*v)),
+// replicate border, non-finite flow = no warp.  Every float operation is written out in the order of
+// the CPU restatement used by the tests (DESIGN.md "lk_iter") and the file is built with -ffp-contract=off, so the bytes match.
+struct WarpArgs {
+    const uint8_t *src;
+    uint8_t *dst;
+    const float *flow; // interleaved (u,v), row (y - flow_row0)
+    float scale;
+    int w, h, pitch, row0, out_y0, out_y1, flow_row0, blocks_x;
+};
+
+struct WarpTable {
+    WarpArgs lv[OFX_MAX_LEVELS];
+    int first_block[OFX_MAX_LEVELS + 1];
+    int n;
+};
+
+__device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
+{
+    if (blk >= T.first_block[T.n]) return;
+    int level = 0;
+    while (level + 1 < T.n && blk >= T.first_block[level + 1]) ++level;
+    const WarpArgs &A = T.lv[level];
+    const int block = blk - T.first_block[level];
+    const int bx = block % A.blocks_x, by = block / A.blocks_x;
+    const int x0 = 4 * (bx * 256 + tid);
+    const int y = A.out_y0 + by;
+    if (x0 >= A.pitch || y >= A.out_y1) return;
+    const float *frow = A.flow + 2 * ((size_t)(y - A.flow_row0) * (size_t)A.w);
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = x0 + k;
+        if (x >= A.w) break;
+        const float2 f = reinterpret_cast<const float2 *>(frow)[x];
+        float sx = (float)x + A.scale * f.x;
+        float sy = (float)y + A.scale * f.y;
+        uint32_t val;
+        if (!(sx >= -1e9f && sx <= 1e9f) || !(sy >= -1e9f && sy <= 1e9f)) {
+            val = A.src[(size_t)(y - A.row0) * (size_t)A.pitch + x];
+        } else {
+            sx = sx < 0.0f ? 0.0f : (sx > (float)(A.w - 1) ? (float)(A.w - 1) : sx);
+            sy = sy < 0.0f ? 0.0f : (sy > (float)(A.h - 1) ? (float)(A.h - 1) : sy);
+            const int xi = (int)sx, yi = (int)sy;
+            const int x1 = xi + 1 < A.w ? xi + 1 : A.w - 1, y1 = yi + 1 < A.h ? yi + 1 : A.h - 1;
+            const float fx = sx - (float)xi, fy = sy - (float)yi;
+            const uint8_t *r0 = A.src + (size_t)(yi - A.row0) * (size_t)A.pitch;
+            const uint8_t *r1 = A.src + (size_t)(y1 - A.row0) * (size_t)A.pitch;
+            const float p00 = r0[xi], p01 = r0[x1], p10 = r1[xi], p11 = r1[x1];
+            const float a = p00 + fx * (p01 - p00);
+            const float b = p10 + fx * (p11 - p10);
+            const float v = a + fy * (b - a);
+            val = (uint32_t)(int)(v + 0.5f);
+        }
+        out |= (val & 0xffu) << (8 * k);
+    }
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+}
+
 } // namespace ofx_dev

@@ -45,11 +45,12 @@ class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
-                 shard=None):
+                 shard=None, iters: int = 1):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
         p.width, p.height, p.levels, p.window, p.mode, p.device = width, height, levels, window, MODES[mode], device
+        p.iters = iters
         self.shard = shard
         if shard is not None:
             p.sharded = 1
@@ -297,12 +298,30 @@ def compose_flow(flow_levels: List[np.ndarray], levels: int, level: int) -> np.n
     return out.cpu().numpy()
 
 
-def flow_pair(prev1: np.ndarray, next1: np.ndarray, levels: int, window: int, mode: str) -> List[np.ndarray]:
+def warp_u8(src1: np.ndarray, flow: np.ndarray, scale: float) -> np.ndarray:
+    import torch
+    from .lib import Geom
+
+    class WarpDesc(C.Structure):
+        _fields_ = [("d_src", _vp), ("d_dst", _vp), ("geom", Geom), ("d_flow", _vp), ("flow_row0", C.c_int), ("scale", C.c_float)]
+
+    L = _lib.load()
+    h, w = src1.shape
+    ts, pitch = _u8_plane(src1)
+    td = torch.zeros_like(ts)
+    tf = torch.from_numpy(np.ascontiguousarray(flow, dtype=np.float32)).cuda()
+    d = WarpDesc(ts.data_ptr(), td.data_ptr(), Geom.full(w, h, pitch), tf.data_ptr(), 0, scale)
+    check(L.ofx_warp_levels(C.byref(d), 1, _stream_ptr()), "ofx_warp_levels")
+    torch.cuda.synchronize()
+    return td[:, :w].cpu().numpy()
+
+
+def flow_pair(prev1: np.ndarray, next1: np.ndarray, levels: int, window: int, mode: str, iters: int = 1) -> List[np.ndarray]:
     """Whole pair through a Session: returns the flow pyramid as host arrays."""
     import torch
 
     h, w = prev1.shape
-    s = Session(w, h, levels, window, mode)
+    s = Session(w, h, levels, window, mode, iters=iters)
     try:
         s.push_frame_host(prev1)
         s.set_frame_host(next1)

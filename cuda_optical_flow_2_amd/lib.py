@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("own_y0", C.c_int * OFX_MAX_LEVELS), ("own_y1", C.c_int * OFX_MAX_LEVELS),
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
                 ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
-                ("reserved", C.c_int * 8)]
+                ("iters", C.c_int), ("reserved", C.c_int * 7)]
 
 
 _vp = C.c_void_p
@@ -57,6 +57,7 @@ _SIGS = {
     "ofx_pyramid_1ch": [_vp, _i, _i, _i, C.POINTER(_vp), C.POINTER(_i), _i, _vp],
     "ofx_shift_vector": [C.POINTER(_vp), _i, _i, _vp, _vp],
     "ofx_shift_1ch": [_vp, _vp, _gp, _vp, _vp],
+    "ofx_warp_levels": [_vp, _i, _vp],
     "ofx_compose_flow": [C.POINTER(_vp), _i, _i, _i, _i, _vp, _vp],
     "ofx_extract_ch0": [_vp, _vp, _i, _i, _i, _vp],
     "ofx_replicate_3ch": [_vp, _i, _vp, _i, _i, _vp],

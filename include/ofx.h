@@ -94,6 +94,7 @@ typedef struct ofx_lk_desc {
      * device; the kernel reads d_next THROUGH the reference's global shift by that vector (cpu::shift_back_pyramid,
      * OptFlowCPU.cpp:241-282, fused into the row loads) -- same bits as shifting first, without the extra pass. */
     const float *d_uv;
+    int accumulate; /* non-zero: d_flow += result (refinement iterations, ofx_warp_levels) instead of d_flow = result */
 } ofx_lk_desc;
 int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
 
@@ -172,6 +173,21 @@ int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream);
  * the buffer make the affected pixels undefined; the caller sizes halos. */
 int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream);
 
+/* Extension (the reference has no iterations): d_dst(x,y) = round_u8(bilinear(d_src, x + scale*u, y + scale*v))
+ * with (u,v) = d_flow at (x,y), replicate border, non-finite flow = no warp; whole levels only.  One refinement
+ * iteration of a level = this warp of the (shifted) next image by the flow so far, then ofx_lk_levels with
+ * accumulate = 1.  scale = OFX_ITER_SCALE turns the reference's flow units into pixels (Sobel gain 8 / Dt_3x3 gain 15). */
+#define OFX_ITER_SCALE 0.533333361148834228515625f
+typedef struct ofx_warp_desc {
+    const uint8_t *d_src;
+    uint8_t *d_dst;
+    ofx_geom geom;
+    const float *d_flow;
+    int flow_row0;
+    float scale;
+} ofx_warp_desc;
+int ofx_warp_levels(const ofx_warp_desc *levels, int n, void *stream);
+
 /* main.cu:138-147: dense flow at `level` = sum_k 2^(k-level) flow_k(y>>s, x>>s). */
 int ofx_compose_flow(const float *const *d_flow_levels, int w, int h, int levels, int level, float *d_dst,
                      void *stream);
@@ -239,7 +255,9 @@ typedef struct ofx_params {
      * comp == own: halos come from the neighbours (exchange); comp == buf: halos are recomputed locally from a
      * wider halo one level below (no exchange).  Ignored (treated as own) when comp_y1[k] == 0. */
     int comp_y0[OFX_MAX_LEVELS], comp_y1[OFX_MAX_LEVELS];
-    int reserved[8];
+    /* refinement iterations per level (extension, lk_float only): 0 or 1 = the reference (no refinement) */
+    int iters;
+    int reserved[7];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);

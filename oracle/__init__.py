@@ -214,6 +214,36 @@ class Oracle:
                 self.calc_opt_flow_gpu(pp[k], npyr[k], flow, k, levels, window, exact_sums)
         return flow, pp, npyr
 
+    # ---- extension: iterative refinement (no reference twin; DESIGN.md "lk_iter")
+    ITER_SCALE = np.float32(8.0 / 15.0)
+
+    def warp_bilinear_u8(self, src1, flow, scale=None):
+        src1, flow = _c(src1, np.uint8), _c(flow, np.float32)
+        h, w = src1.shape
+        d = np.empty_like(src1)
+        self.lib.orc_warp_bilinear_u8(_p(src1, _u8p), w, h, _p(flow, _f32p), C.c_float(self.ITER_SCALE if scale is None else scale), _p(d, _u8p))
+        return d
+
+    def lk_iter_level(self, prev1, next1_shifted, window, iters):
+        prev1, next1_shifted = _c(prev1, np.uint8), _c(next1_shifted, np.uint8)
+        h, w = prev1.shape
+        flow = np.empty((h, w, 2), np.float32)
+        first = np.empty((h, w, 2), np.float32)
+        self.lib.orc_lk_iter_level(_p(prev1, _u8p), _p(next1_shifted, _u8p), w, h, window, iters, _p(flow, _f32p), _p(first, _f32p))
+        return flow, first
+
+    def flow_pair_iter(self, prev1, next1, levels, window, iters):
+        """lk_float pyramid with `iters` refinement iterations per level.  Returns the flow pyramid (accumulated)."""
+        pp = self.gauss_pyramid(np.repeat(prev1[:, :, None], 3, 2), levels)
+        npyr = self.gauss_pyramid(np.repeat(next1[:, :, None], 3, 2), levels)
+        h, w = prev1.shape
+        first = [np.zeros((h >> k, w >> k, 2), np.float32) for k in range(levels)]
+        out = [None] * levels
+        for k in range(levels - 1, -1, -1):
+            nxt3 = npyr[k] if k == levels - 1 else self.shift_back_pyramid(npyr[k], k, levels, first)
+            out[k], first[k] = self.lk_iter_level(pp[k][:, :, 0], nxt3[:, :, 0], window, iters)
+        return out
+
     # ---- bilateral
     def generate_gaussian_kernel(self, sigma, ks):
         n = ks if ks % 2 else ks + 1

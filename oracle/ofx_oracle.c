@@ -538,3 +538,62 @@ void orc_extract_ch0(const uint8_t *src3, uint8_t *dst1, int n)
 {
     for (int i = 0; i < n; ++i) dst1[i] = src3[3 * i];
 }
+
+/* ------------------------------------------------------------------------ */
+/* Extension (no reference twin): see ofx_oracle.h.  Every operation is a single-rounding float op in the order
+ * written (build with -ffp-contract=off); the HIP warp kernel performs the same sequence. */
+void orc_warp_bilinear_u8(const uint8_t *src1, int w, int h, const float *flow_uv, float scale, uint8_t *dst1)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const size_t p = (size_t)y * w + x;
+            float sx = (float)x + scale * flow_uv[2 * p];
+            float sy = (float)y + scale * flow_uv[2 * p + 1];
+            if (!(sx >= -1e9f && sx <= 1e9f) || !(sy >= -1e9f && sy <= 1e9f)) { /* non-finite flow: no warp */
+                dst1[p] = src1[p];
+                continue;
+            }
+            /* replicate border */
+            sx = sx < 0.0f ? 0.0f : (sx > (float)(w - 1) ? (float)(w - 1) : sx);
+            sy = sy < 0.0f ? 0.0f : (sy > (float)(h - 1) ? (float)(h - 1) : sy);
+            const int x0 = (int)sx, y0 = (int)sy; /* sx, sy >= 0: truncation == floor */
+            const int x1 = x0 + 1 < w ? x0 + 1 : w - 1, y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+            const float fx = sx - (float)x0, fy = sy - (float)y0;
+            const float p00 = src1[(size_t)y0 * w + x0], p01 = src1[(size_t)y0 * w + x1];
+            const float p10 = src1[(size_t)y1 * w + x0], p11 = src1[(size_t)y1 * w + x1];
+            const float a = p00 + fx * (p01 - p00);
+            const float b = p10 + fx * (p11 - p10);
+            const float v = a + fy * (b - a);
+            dst1[p] = (uint8_t)(int)(v + 0.5f);
+        }
+}
+
+void orc_lk_iter_level(const uint8_t *prev1, const uint8_t *next1_shifted, int w, int h, int window, int iters,
+                       float *flow_uv, float *flow_first)
+{
+    const size_t n = (size_t)w * (size_t)h;
+    uint8_t *p3 = (uint8_t *)malloc(3 * n), *n3 = (uint8_t *)malloc(3 * n), *warped = (uint8_t *)malloc(n);
+    float *delta = (float *)malloc(2 * n * sizeof(float));
+    float *levels[1] = {delta};
+    orc_replicate_1ch_to_3ch(prev1, p3, (int)n);
+    for (int it = 0; it < iters; ++it) {
+        if (it == 0) {
+            orc_replicate_1ch_to_3ch(next1_shifted, n3, (int)n);
+        } else {
+            orc_warp_bilinear_u8(next1_shifted, w, h, flow_uv, ORC_ITER_SCALE, warped);
+            orc_replicate_1ch_to_3ch(warped, n3, (int)n);
+        }
+        /* one level, already shifted: level == max_level - 1 skips the shift inside */
+        orc_calc_opt_flow_gpu(p3, n3, w, h, levels, 0, 1, window, 1);
+        if (it == 0) {
+            memcpy(flow_uv, delta, 2 * n * sizeof(float));
+            if (flow_first) memcpy(flow_first, delta, 2 * n * sizeof(float));
+        } else {
+            for (size_t i = 0; i < 2 * n; ++i) flow_uv[i] = flow_uv[i] + delta[i];
+        }
+    }
+    free(delta);
+    free(warped);
+    free(n3);
+    free(p3);
+}

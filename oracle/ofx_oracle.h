@@ -118,6 +118,17 @@ void orc_generate_gaussian_kernel(double sigma_s, int kernel_size, double *dst);
 void orc_bilateral_3ch(const uint8_t *src3, const uint8_t *gray3, uint8_t *dst3, int w, int h,
                        int ww, int wh, double sigma_s, double sigma_b);
 
+/* ---- extension: iterative refinement with bilinear warp (NO reference twin) ------------------------
+ * Defined by DESIGN.md section "lk_iter"; pinned only by this restatement and by known-answer translations.
+ *   iteration 1   = the reference level (orc_calc_opt_flow_gpu semantics on the globally shifted next image)
+ *   iteration i>1 : W = round_u8(bilinear(next', x + s*u, y + s*v)), s = 8/15 (Sobel gain 8 / Dt_3x3 gain 15),
+ *                   F += level(prev, W)  with exact window sums
+ * The shift vectors between levels stay the reference's (pixel 0 of the FIRST iteration's flow). */
+#define ORC_ITER_SCALE 0.533333361148834228515625f /* (float)(8.0/15.0) */
+void orc_warp_bilinear_u8(const uint8_t *src1, int w, int h, const float *flow_uv, float scale, uint8_t *dst1);
+void orc_lk_iter_level(const uint8_t *prev1, const uint8_t *next1_shifted, int w, int h, int window, int iters,
+                       float *flow_uv /* out: accumulated */, float *flow_first /* out, may be NULL: iteration 1 only */);
+
 /* ---- helpers for 1-channel pipelines (layout only, no arithmetic) ------- */
 void orc_replicate_1ch_to_3ch(const uint8_t *src1, uint8_t *dst3, int n);
 void orc_extract_ch0(const uint8_t *src3, uint8_t *dst1, int n);

@@ -360,6 +360,47 @@ def test_sharded_driver_single_rank_pipelined(eng):
     drv.session.close()
 
 
+# ---- extension: refinement iterations (pinned by the oracle restatement only) ----------------------------
+
+def test_warp_bilinear_matches_oracle(eng, oracle):
+    rng = np.random.default_rng(3)
+    for (w, h) in ((64, 48), (301, 37), (2, 2), (1, 5)):
+        img = synth.random_pair(w, h, seed=w)[0]
+        flow = (rng.normal(size=(h, w, 2)) * 6).astype(np.float32)
+        flow[0, 0] = (np.nan, 1.0)
+        flow[h - 1, w - 1] = (1e30, -1e30)
+        flow[h // 2, w // 2] = (np.inf, 0.0)
+        assert_same(eng.warp_u8(img, flow, float(oracle.ITER_SCALE)), oracle.warp_bilinear_u8(img, flow), f"warp {w}x{h}")
+
+
+@pytest.mark.parametrize("cfg", [(160, 120, 1, 9, 3), (320, 240, 3, 7, 5), (256, 192, 4, 5, 2)])
+def test_iterative_refinement_matches_oracle(eng, oracle, cfg):
+    """iters > 1: iteration 1 is the reference level, each further one warps the shifted next image by the flow so far
+    (bilinear, u8) and accumulates; the shift vectors between levels stay the reference's.  Bit-exact vs the restatement."""
+    w, h, L, win, iters = cfg
+    p, n = synth.smooth_pair(w, h, 1.2, -0.8)
+    got = eng.flow_pair(p, n, L, win, "lk_float", iters=iters)
+    want = oracle.flow_pair_iter(p, n, L, win, iters)
+    for k in range(L):
+        assert_same(got[k], want[k], f"iters={iters} L{k}")
+    one = eng.flow_pair(p, n, L, win, "lk_float", iters=1)
+    ref, _, _ = oracle.flow_pair(synth.to_3ch(p), synth.to_3ch(n), L, win, "lk_float", exact_sums=True)
+    for k in range(L):
+        assert_same(one[k], ref[k], f"iters=1 is the reference, L{k}")
+
+
+def test_iterative_refinement_converges_to_the_translation(eng):
+    """Known answer: a smooth texture translated by (0.6,-0.4) px.  Flow is in the reference's units (15/8 of a pixel,
+    SURVEY 8a row 10); refinement must move the median estimate closer to the truth than the single reference pass."""
+    p, n = synth.smooth_pair(640, 480, 0.6, -0.4)
+    truth = np.array([0.6, -0.4])
+    err = []
+    for iters in (1, 4):
+        fl = eng.flow_pair(p, n, 1, 9, "lk_float", iters=iters)[0]
+        err.append(np.abs(np.nanmedian(fl.reshape(-1, 2), axis=0) * 8.0 / 15.0 - truth).max())
+    assert err[1] < err[0] and err[1] < 0.02, err
+
+
 def test_session_rejects_bad_configs(eng):
     from cuda_optical_flow_2_amd.lib import OfxError
 
