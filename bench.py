@@ -24,6 +24,7 @@ WORKLOADS = {  # BASELINE.json configs: (width, height, levels, window)
     "4k": (3840, 2160, 5, 9),
     "8k": (7680, 4320, 6, 15),
 }
+BASELINE_ITERS = {"vga": 3, "1080p": 5, "4k": 5, "8k": 10}  # the "iters" of BASELINE.json's configs
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 LK_BYTES_PER_PX = 10   # fused level kernel: 2 u8 read + one (u,v) float pair written
 
@@ -84,8 +85,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("OFX_BENCH_FORCE_DIST") == "1"  # rehearsal: run the N > 1 driver (RCCL init, broadcast) on one rank
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     w, h, levels, window = WORKLOADS[args.workload]
@@ -94,7 +99,7 @@ def main():
     frames = [synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1] for i in range(nframes)]
     d_frames = [torch.from_numpy(f).cuda() for f in frames]
 
-    if world == 1:
+    if world == 1 and not force_dist:
         if args.iters > 1:
             args.path = "plain"
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters)
@@ -134,14 +139,14 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
     fence()
-    sess.timing(args.steps)
+    sess.timing(args.steps * max(1, args.iters))
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -151,7 +156,7 @@ def main():
     sess.timing(0)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -163,9 +168,9 @@ def main():
                      for k in range(levels))
         lk_bytes = LK_BYTES_PER_PX * own_px
         if args.iters > 1:
-            # timed span = shift + LK + (iters-1) x (warp + accumulating LK): shift 2 B/px, warp 1+8+1 B/px, LK + 8 B/px
-            lk_bytes += 2 * own_px + (args.iters - 1) * (10 + 18) * own_px
-        if world == 1 and args.path == "stream":
+            # every LK launch is timed: the first writes the flow (10 B/px), the others also read it back (18 B/px)
+            lk_bytes = (10 + (args.iters - 1) * 18) * own_px // args.iters
+        if driver is None and args.path == "stream":
             # the stream launch also builds the next frame's pyramid: + 5 B per destination pixel of levels 1..
             lk_bytes += 5 * sum((w >> k) * (h >> k) for k in range(1, levels))
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
@@ -192,12 +197,13 @@ def main():
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
-                "sharding": "none" if world == 1 else f"row blocks over {world} ranks, RCCL halo exchange per level",
+                "sharding": "none" if driver is None else f"row blocks over {world} rank(s): halos recomputed from a wider level-0 halo, "
+                            "one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)",
             },
             "roofline": {
                 "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels for pair j-2 | corner flows of pair j-1 | pyramid of "
                             "frame j; bytes = 10 B/px LK + 5 B/px pyramid)"
-                           if world == 1 and args.path == "stream" else
+                           if driver is None and args.path == "stream" else
                            "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -205,10 +211,32 @@ def main():
                 "launches_timed": k_n, "traffic": traffic,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not force_dist and args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS:
+            # BASELINE.json's configs carry "N iters"; the reference has no iterations, so they run as the
+            # lk_iter extension here, next to the reference-defined line above (same process, same frames, plain path)
+            it = BASELINE_ITERS[args.workload]
+            s2 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it)
+            s2.set_frame_device(d_frames[0]); s2.build_pyramid(); s2.swap()
+            def step2(i):
+                s2.set_frame_device(d_frames[(i + 1) % nframes]); s2.build_pyramid(); s2.run_flow(); s2.swap()
+            n2 = max(10, min(args.steps, 50))
+            for i in range(5):
+                step2(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n2):
+                step2(5 + i)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t0) / n2 * 1e3
+            out["extra"] = {"baseline_config_with_iters": {
+                "workload": f"{w}x{h}, {levels} levels, {window}x{window}, iters={it} (extension lk_iter: bilinear-warp refinement)",
+                "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms2, 5),
+                "frames_per_s": round(1e3 / ms2, 1), "steps": n2}}
+            s2.close()
+        if driver is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, h, levels, window)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

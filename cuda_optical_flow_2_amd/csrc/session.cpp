@@ -349,47 +349,53 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
 
 // Every level's fused LK in one launch, using the uv slots as they stand; below the top level the kernel reads `next`
 // through the global shift (no separate shift pass, no shifted planes).
+// one multi-level LK launch, bracketed by timing events when the session is armed (ofx_session_timing)
+static int timed_lk_launch(ofx_session *s, const ofx_lk_desc *lk, int nl, void *stream)
+{
+    const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
+    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
+    OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
+    if (timed) {
+        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
+        s->ev_used += 2;
+    }
+    return OFX_OK;
+}
+
 static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
 {
     const int L = s->p.levels;
     ofx_lk_desc lk[OFX_MAX_LEVELS];
-    const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
-    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
     if (s->p.iters <= 1) {
         int nl = 0;
         for (int k = L - 1; k >= 0; --k) // coarse levels first: their few waves start at once and finish early
             lk[nl++] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k],
                                    k == L - 1 ? nullptr : uv + 2 * k, 0};
-        OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
-    } else {
-        // Extension (DESIGN.md "lk_iter"): iteration 1 is the reference level; every further iteration warps
-        // the shifted next image by the flow so far (bilinear, rounded to u8) and adds the flow of (prev, warped).
-        // sh[0] holds the globally shifted next image (the warp source), sh[1] the warped image.
-        ofx_shift_desc sd[OFX_MAX_LEVELS];
-        int ns = 0;
-        for (int k = L - 2; k >= 0; --k)
-            sd[ns++] = ofx_shift_desc{s->plane[1][k], s->sh[0][k], level_geom(s, k, 0, s->h[k]), uv + 2 * k};
-        if (ns) OFX_TRY(ofx_shift_levels(sd, ns, stream));
-        auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
-        int nl = 0;
-        for (int k = L - 1; k >= 0; --k)
-            lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0};
-        OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
-        for (int it = 1; it < s->p.iters; ++it) {
-            ofx_warp_desc wd[OFX_MAX_LEVELS];
-            nl = 0;
-            for (int k = L - 1; k >= 0; --k) {
-                wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE};
-                lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1};
-                ++nl;
-            }
-            OFX_TRY(ofx_warp_levels(wd, nl, stream));
-            OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
-        }
+        return timed_lk_launch(s, lk, nl, stream);
     }
-    if (timed) {
-        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
-        s->ev_used += 2;
+    // Extension (DESIGN.md "lk_iter"): iteration 1 is the reference level; every further iteration warps
+    // the shifted next image by the flow so far (bilinear, rounded to u8) and adds the flow of (prev, warped).
+    // sh[0] holds the globally shifted next image (the warp source), sh[1] the warped image.
+    ofx_shift_desc sd[OFX_MAX_LEVELS];
+    int ns = 0;
+    for (int k = L - 2; k >= 0; --k)
+        sd[ns++] = ofx_shift_desc{s->plane[1][k], s->sh[0][k], level_geom(s, k, 0, s->h[k]), uv + 2 * k};
+    if (ns) OFX_TRY(ofx_shift_levels(sd, ns, stream));
+    auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
+    int nl = 0;
+    for (int k = L - 1; k >= 0; --k)
+        lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0};
+    OFX_TRY(timed_lk_launch(s, lk, nl, stream));
+    for (int it = 1; it < s->p.iters; ++it) {
+        ofx_warp_desc wd[OFX_MAX_LEVELS];
+        nl = 0;
+        for (int k = L - 1; k >= 0; --k) {
+            wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE};
+            lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1};
+            ++nl;
+        }
+        OFX_TRY(ofx_warp_levels(wd, nl, stream));
+        OFX_TRY(timed_lk_launch(s, lk, nl, stream));
     }
     return OFX_OK;
 }

@@ -118,7 +118,7 @@ class HipBackend:
             s.stage_frame(frame, self._aux_ptr)
             if rank == 0:
                 s.corner_flows(self._aux)
-            if world > 1:
+            if world > 1 or (dist.is_available() and dist.is_initialized()):
                 if rank == 0:
                     self.uv_stage.copy_(self.uv_all)
                 dist.broadcast(self.uv_stage, src=0)   # issued against the current (= aux) stream
