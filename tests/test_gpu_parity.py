@@ -478,7 +478,7 @@ def test_gpu_bilinear_filter_golden(gpu, golden):
 
 # ---- BASELINE full sizes: size-independent properties -----------------------------------------------------------------
 
-FULL = [(1920, 1080, 4, 7), (3840, 2160, 5, 9)]
+FULL = [(1920, 1080, 4, 7), (3840, 2160, 5, 9), (7680, 4320, 6, 15)]  # BASELINE configs 2, 3 and 5 (the maximum size)
 
 
 @pytest.mark.parametrize("cfg", FULL)
