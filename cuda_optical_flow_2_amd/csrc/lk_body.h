@@ -238,6 +238,155 @@ __device__ __forceinline__ void derivs(const Row<OFX_MODE_COMPAT_CPU> &t, const 
     }
 }
 
+// ---- packed (in | out) form -------------------------------------------------------------------------------------------
+// The march keeps TWO derivative rows in flight: the one entering the vertical window and the one leaving it.  They go
+// through exactly the same arithmetic, on values that fit 16 bits (|Ix|,|Iy| <= 1020, |It| <= 4335 before the centre tap
+// is removed), so both are carried in ONE register per quantity: low half = entering row, high half = leaving row.
+// v_pk_*_i16 then does both rows per instruction, one DPP move carries both neighbours, and
+//     V += Ix_in*Iy_in - Ix_out*Iy_out      is ONE   v_dot2_i32_i16( (Ix_in,Ix_out), (Iy_in,-Iy_out), V ).
+// It also halves the row state in registers.  (OFX_LK_PACKED=0 keeps the earlier fp32 formulation for A/B runs.)
+#ifndef OFX_LK_PACKED
+#define OFX_LK_PACKED 1
+#endif
+typedef short s2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ s2 lane_shift_s2(s2 v, bool from_left)
+{
+    return as_s2((uint32_t)(from_left ? lane_shift_right((int)as_u32(v)) : lane_shift_left((int)as_u32(v))));
+}
+
+__device__ __forceinline__ s2 pk_two()
+{
+    uint32_t v = 0x00020002u;
+    asm volatile("" : "+v"(v));
+    return as_s2(v);
+}
+
+template <int MODE>
+struct RowPk; // one image row of this lane's 4 columns for both marching windows (lo: entering, hi: leaving)
+template <>
+struct RowPk<OFX_MODE_LK_FLOAT> {
+    s2 p[4]; // prev
+    s2 d[4]; // next - prev
+};
+template <>
+struct RowPk<OFX_MODE_COMPAT_CPU> {
+    s2 p[4]; // prev
+    s2 n[4]; // next
+};
+
+// byte j of `in_raw` -> low half, byte j of `out_raw` -> high half (zero-extended): one v_perm_b32 per column
+template <int J>
+__device__ __forceinline__ s2 pair_bytes(uint32_t in_raw, uint32_t out_raw)
+{
+    constexpr uint32_t sel = (uint32_t)J | (0x0cu << 8) | ((uint32_t)(4 + J) << 16) | (0x0cu << 24);
+    return as_s2(__builtin_amdgcn_perm(out_raw, in_raw, sel));
+}
+
+__device__ __forceinline__ void unpack_pk(uint32_t pi, uint32_t ni, uint32_t po, uint32_t no, RowPk<OFX_MODE_LK_FLOAT> &r)
+{
+    r.p[0] = pair_bytes<0>(pi, po);
+    r.p[1] = pair_bytes<1>(pi, po);
+    r.p[2] = pair_bytes<2>(pi, po);
+    r.p[3] = pair_bytes<3>(pi, po);
+    r.d[0] = pair_bytes<0>(ni, no) - r.p[0];
+    r.d[1] = pair_bytes<1>(ni, no) - r.p[1];
+    r.d[2] = pair_bytes<2>(ni, no) - r.p[2];
+    r.d[3] = pair_bytes<3>(ni, no) - r.p[3];
+}
+
+__device__ __forceinline__ void unpack_pk(uint32_t pi, uint32_t ni, uint32_t po, uint32_t no, RowPk<OFX_MODE_COMPAT_CPU> &r)
+{
+    r.p[0] = pair_bytes<0>(pi, po);
+    r.p[1] = pair_bytes<1>(pi, po);
+    r.p[2] = pair_bytes<2>(pi, po);
+    r.p[3] = pair_bytes<3>(pi, po);
+    r.n[0] = pair_bytes<0>(ni, no);
+    r.n[1] = pair_bytes<1>(ni, no);
+    r.n[2] = pair_bytes<2>(ni, no);
+    r.n[3] = pair_bytes<3>(ni, no);
+}
+
+// derivatives of the middle rows of both windows; mk[j] = 16-bit-lane masks (column inside the image AND that window's
+// row inside the image and already part of the strip); only Ix and Iy are masked (every product has one as a factor)
+__device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_LK_FLOAT> &t, const RowPk<OFX_MODE_LK_FLOAT> &m,
+                                          const RowPk<OFX_MODE_LK_FLOAT> &b, const uint32_t (&mk)[4], s2 (&ix)[4], s2 (&iy)[4],
+                                          s2 (&it)[4])
+{
+    s2 sm[6], df[6], g[6];
+    const s2 two = pk_two(); // opaque (2,2): keeps the [1 2 1] combinations as one v_pk_mad_i16 instead of shift + add
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sm[j + 1] = m.p[j] * two + (t.p[j] + b.p[j]); // [1 2 1]^T (kernels.cpp:6-19)
+        df[j + 1] = b.p[j] - t.p[j];                  // [-1 0 1]^T
+        g[j + 1] = m.d[j] * two + (t.d[j] + b.d[j]);  // Dt_3x3 = [1 2 1]^T[1 2 1] - centre (kernels.cpp:20-24) on next - prev
+    }
+    sm[0] = lane_shift_s2(sm[4], true);
+    sm[5] = lane_shift_s2(sm[1], false);
+    df[0] = lane_shift_s2(df[4], true);
+    df[5] = lane_shift_s2(df[1], false);
+    g[0] = lane_shift_s2(g[4], true);
+    g[5] = lane_shift_s2(g[1], false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ix[j] = as_s2(as_u32(sm[j + 2] - sm[j]) & mk[j]);
+        iy[j] = as_s2(as_u32(df[j + 1] * two + (df[j] + df[j + 2])) & mk[j]);
+        it[j] = g[j + 1] * two + (g[j] + g[j + 2]) - m.d[j];
+    }
+}
+
+__device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_COMPAT_CPU> &t, const RowPk<OFX_MODE_COMPAT_CPU> &m,
+                                          const RowPk<OFX_MODE_COMPAT_CPU> &b, const uint32_t (&mk)[4], s2 (&ix)[4], s2 (&iy)[4],
+                                          s2 (&it)[4])
+{
+    // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap contributes
+    // floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64); u8 wrap (:106, :15)
+    s2 sm[6], df[6], sp[6], sn[6], mp[4], mn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sm[j + 1] = (m.p[j] + m.p[j]) + t.p[j] + b.p[j];
+        df[j + 1] = b.p[j] - t.p[j];
+        sp[j + 1] = (t.p[j] >> 4) + (m.p[j] >> 3) + (b.p[j] >> 4); // column contribution left/right of the centre
+        sn[j + 1] = (t.n[j] >> 4) + (m.n[j] >> 3) + (b.n[j] >> 4);
+        mp[j] = (t.p[j] >> 3) + (m.p[j] >> 2) + (b.p[j] >> 3);     // ... as the centre column
+        mn[j] = (t.n[j] >> 3) + (m.n[j] >> 2) + (b.n[j] >> 3);
+    }
+    sm[0] = lane_shift_s2(sm[4], true);
+    sm[5] = lane_shift_s2(sm[1], false);
+    df[0] = lane_shift_s2(df[4], true);
+    df[5] = lane_shift_s2(df[1], false);
+    sp[0] = lane_shift_s2(sp[4], true);
+    sp[5] = lane_shift_s2(sp[1], false);
+    sn[0] = lane_shift_s2(sn[4], true);
+    sn[5] = lane_shift_s2(sn[1], false);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t m8 = mk[j] & 0x00ff00ffu;
+        ix[j] = as_s2(as_u32(sm[j + 2] - sm[j]) & m8);
+        iy[j] = as_s2(as_u32((df[j + 1] + df[j + 1]) + df[j] + df[j + 2]) & m8);
+        const s2 gp = sp[j] + mp[j] + sp[j + 2], gn = sn[j] + mn[j] + sn[j + 2];
+        it[j] = as_s2(as_u32(gn - gp) & 0x00ff00ffu);
+    }
+}
+
+// V += P(entering) - P(leaving) for the five products, order of the planes: OptFlowCPU.cpp:347-358
+__device__ __forceinline__ void accumulate_pk(const s2 (&ix)[4], const s2 (&iy)[4], const s2 (&it)[4], int (&vxx)[4], int (&vyy)[4],
+                                              int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
+{
+    const s2 flip = {1, -1}; // negate the leaving row's factor
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const s2 nx = ix[j] * flip, ny = iy[j] * flip, nt = it[j] * flip;
+        vxx[j] = __builtin_amdgcn_sdot2(ix[j], nx, vxx[j], false);
+        vyy[j] = __builtin_amdgcn_sdot2(iy[j], ny, vyy[j], false);
+        vxy[j] = __builtin_amdgcn_sdot2(ix[j], ny, vxy[j], false);
+        vxt[j] = __builtin_amdgcn_sdot2(ix[j], nt, vxt[j], false);
+        vyt[j] = __builtin_amdgcn_sdot2(iy[j], nt, vyt[j], false);
+    }
+}
+
 // a*b as an exact int32 through the fp32 pipe: for integer-valued |a*b| < 2^22, fma(a, b, 1.5*2^23) has the product
 // in its low mantissa bits, so bits(fma) - bits(1.5*2^23) == a*b.  (fma f32: 2 cycles; v_mul_i32_i24: 4.)
 #define OFX_MAGIC 12582912.0f
@@ -402,6 +551,44 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     // slot index is a compile-time constant (no register-to-register rotation).
     const int y_first = ys - R; // first derivative row this strip needs
     const int nsteps = (ye - ys) + 2 * R;
+#if OFX_LK_PACKED
+    // Row r of both windows lives in slot (r - (y_first - 1)) mod 3 (the loop is unrolled three times so that every slot
+    // index is a compile-time constant); the high halves carry the stream of the leaving window, which is the same rows
+    // NS steps later: its rows before y_first - 1 are fed as zeros and its derivative rows before y_first are masked,
+    // so the strip's priming steps need no code of their own.
+    RowPk<MODE> wp[3];
+    unpack_pk(load_row(A.prev, y_first - 1), load_next(y_first - 1), 0u, 0u, wp[0]);
+    unpack_pk(load_row(A.prev, y_first), load_next(y_first), 0u, 0u, wp[1]);
+    auto out_row = [&](const uint8_t *img, int r, bool is_next) -> uint32_t {
+        if (r < y_first - 1) return 0u;
+        return is_next ? load_next(r) : load_row(img, r);
+    };
+    uint32_t pf_ip = load_row(A.prev, y_first + 1), pf_in = load_next(y_first + 1);
+    uint32_t pf_op = out_row(A.prev, y_first + 1 - NS, false), pf_on = out_row(A.next, y_first + 1 - NS, true);
+
+    int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
+
+    auto body = [&](auto K, int s) {
+        constexpr int k = decltype(K)::value; // s mod 3
+        const int yy = y_first + s;           // derivative row entering the window
+        const int yo = yy - NS;               // derivative row leaving it
+
+        // take the prefetched rows, prefetch the next ones (consumed one step from now)
+        unpack_pk(pf_ip, pf_in, pf_op, pf_on, wp[(k + 2) % 3]);
+        pf_ip = load_row(A.prev, yy + 2);
+        pf_in = load_next(yy + 2);
+        pf_op = out_row(A.prev, yo + 2, false);
+        pf_on = out_row(A.next, yo + 2, true);
+
+        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
+        // window only counts once its row has entered (yo >= y_first)
+        const uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x0000ffffu : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
+        const uint32_t mk[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
+        s2 ix[4], iy[4], it[4];
+        derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], mk, ix, iy, it);
+        accumulate_pk(ix, iy, it, vxx, vyy, vxy, vxt, vyt);
+
+#else
     Row<MODE> win[3], wout[3];
     {
         const uint32_t p0 = load_row(A.prev, y_first - 1), n0 = load_next(y_first - 1);
@@ -448,6 +635,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
             accumulate<false>(ix, iy, it, ix, iy, it, vxx, vyy, vxy, vxt, vyt);
         }
 
+#endif
         // ---- emit output row y = yy - R ------------------------------------------------------------------------
         if (s >= 2 * R) {
             const int y = yy - R;
