@@ -277,6 +277,16 @@ struct RowPk<OFX_MODE_COMPAT_CPU> {
     s2 n[4]; // next
 };
 
+// makes the row's registers opaque at this point of the program (no instruction is emitted)
+__device__ __forceinline__ void pin_row(RowPk<OFX_MODE_LK_FLOAT> &r)
+{
+    asm volatile("" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]), "+v"(r.d[0]), "+v"(r.d[1]), "+v"(r.d[2]), "+v"(r.d[3]));
+}
+__device__ __forceinline__ void pin_row(RowPk<OFX_MODE_COMPAT_CPU> &r)
+{
+    asm volatile("" : "+v"(r.p[0]), "+v"(r.p[1]), "+v"(r.p[2]), "+v"(r.p[3]), "+v"(r.n[0]), "+v"(r.n[1]), "+v"(r.n[2]), "+v"(r.n[3]));
+}
+
 // byte j of `in_raw` -> low half, byte j of `out_raw` -> high half (zero-extended): one v_perm_b32 per column
 template <int J>
 __device__ __forceinline__ s2 pair_bytes(uint32_t in_raw, uint32_t out_raw)
@@ -456,14 +466,17 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     // whose columns lie outside the image read column 0 of the row and are zeroed by bmask.
     const int y_lim = min(min(ye + R + 1, A.h), A.row_end);
     const int y_min = max(0, A.row0);
-    auto load_row = [&](const uint8_t *img, int y) -> uint32_t {
+    // Loads are split into fetch (issue the memory reads, touch nothing) and finish (mask / permute): the march fetches
+    // one step ahead and finishes at the top of the next step, so that no wave waits on a load it has just issued.
+    auto fetch_row = [&](const uint8_t *img, int y) -> uint32_t {
         uint32_t v = 0u;
         if (y >= y_min && y < y_lim) {
             const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch; // scalar
             v = *reinterpret_cast<const uint32_t *>(row + col_off);
         }
-        return v & bmask;
+        return v;
     };
+    auto finish_row = [&](uint32_t raw) -> uint32_t { return raw & bmask; };
 
     // ---- fused shift ---------------------------------------------------------------------------------------------------
     // Below the top level the reference replaces next by cpu::shift_back_pyramid(next) (OptFlowCPU.cpp:241-282): pixel
@@ -507,41 +520,43 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     // a pixel whose target is outside the image keeps its own byte iff 3*(y*w+x) < w*h, i.e. iff 3*x < w*(h-3*y):
     // all of row y for y < h/3, none for y >= ceil(h/3), and x < w*(h%3)/3 in the one row in between (if h%3 != 0)
     const int y_none = (A.h + 2) / 3, y_part = (A.h % 3) ? A.h / 3 : -1;
-    auto load_next = [&](int y) -> uint32_t {
-        uint32_t v = 0u;
+    struct NextRaw {
+        uint32_t own, sh; // the row's own dword / the dword at the shifted position (0 where not needed)
+        uint32_t have;    // wave-uniform: ~0 when the shifted row exists
+    };
+    auto fetch_next = [&](int y) -> NextRaw {
+        NextRaw r = {0u, 0u, 0u};
         if (y >= y_min && y < y_lim) {
             const float ty = (float)y + sv;
             const bool yin = ty > -1.0f && ty < (float)A.h;
             const int ny = __builtin_amdgcn_readfirstlane(yin ? (int)ty : 0); // uniform: y and v are
             const bool have = yin && ny >= A.row0 && ny < A.row_end;
-            if (have && all_in) {
-                // interior tile, target row inside the image: one unaligned dword, bytes already in place or permuted
-                uint32_t sh;
+            r.have = have ? ~0u : 0u;
+            if (have) {
                 const uint8_t *srow = A.next + (size_t)(uint32_t)(ny - A.row0) * (size_t)(uint32_t)A.pitch;
-                __builtin_memcpy(&sh, srow + nb_off, 4);
-                v = __builtin_amdgcn_perm(0u, sh, sel);
-            } else {
-                uint32_t own = 0u, sh = 0u;
-                if (y < y_none) {
-                    const uint8_t *orow = A.next + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
-                    own = *reinterpret_cast<const uint32_t *>(orow + col_off);
-                    if (y == y_part) {
-                        uint32_t km = 0u;
+                __builtin_memcpy(&r.sh, srow + nb_off, 4); // unaligned dword
+            }
+            // interior tile with its target row inside the image: every byte comes from the shifted dword
+            if (!(have && all_in) && y < y_none) {
+                const uint8_t *orow = A.next + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
+                r.own = *reinterpret_cast<const uint32_t *>(orow + col_off);
+                if (y == y_part) {
+                    uint32_t km = 0u;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (3ll * (cb + j) < (long long)A.w * (A.h % 3)) km |= 0xffu << (8 * j);
-                        own &= km;
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (3ll * (cb + j) < (long long)A.w * (A.h % 3)) km |= 0xffu << (8 * j);
+                    r.own &= km;
                 }
-                if (have) {
-                    const uint8_t *srow = A.next + (size_t)(uint32_t)(ny - A.row0) * (size_t)(uint32_t)A.pitch;
-                    __builtin_memcpy(&sh, srow + nb_off, 4);
-                }
-                v = __builtin_amdgcn_perm(own, sh, have ? sel : own_sel);
             }
         }
-        return v & bmask;
+        return r;
     };
+    // both selectors give 0 for columns outside the image, and own == sh == 0 for rows outside it
+    auto finish_next = [&](const NextRaw &r) -> uint32_t {
+        return __builtin_amdgcn_perm(r.own, r.sh, (sel & r.have) | (own_sel & ~r.have));
+    };
+    auto load_row = [&](const uint8_t *img, int y) -> uint32_t { return finish_row(fetch_row(img, y)); };
+    auto load_next = [&](int y) -> uint32_t { return finish_next(fetch_next(y)); };
 
     // Two 3-row windows march down the strip NS rows apart: `in` around the derivative row entering the vertical
     // window, `out` around the row leaving it.  The leaving row's derivatives are recomputed from the image (its rows
@@ -557,14 +572,13 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     // NS steps later: its rows before y_first - 1 are fed as zeros and its derivative rows before y_first are masked,
     // so the strip's priming steps need no code of their own.
     RowPk<MODE> wp[3];
+    // rows of the leaving window before y_first - 1 are zeros
+    auto fetch_out_prev = [&](int r) -> uint32_t { return r < y_first - 1 ? 0u : fetch_row(A.prev, r); };
+    auto fetch_out_next = [&](int r) -> NextRaw { return r < y_first - 1 ? NextRaw{0u, 0u, 0u} : fetch_next(r); };
     unpack_pk(load_row(A.prev, y_first - 1), load_next(y_first - 1), 0u, 0u, wp[0]);
     unpack_pk(load_row(A.prev, y_first), load_next(y_first), 0u, 0u, wp[1]);
-    auto out_row = [&](const uint8_t *img, int r, bool is_next) -> uint32_t {
-        if (r < y_first - 1) return 0u;
-        return is_next ? load_next(r) : load_row(img, r);
-    };
-    uint32_t pf_ip = load_row(A.prev, y_first + 1), pf_in = load_next(y_first + 1);
-    uint32_t pf_op = out_row(A.prev, y_first + 1 - NS, false), pf_on = out_row(A.next, y_first + 1 - NS, true);
+    unpack_pk(load_row(A.prev, y_first + 1), load_next(y_first + 1), finish_row(fetch_out_prev(y_first + 1 - NS)),
+              finish_next(fetch_out_next(y_first + 1 - NS)), wp[2]);
 
     int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
 
@@ -573,12 +587,11 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         const int yy = y_first + s;           // derivative row entering the window
         const int yo = yy - NS;               // derivative row leaving it
 
-        // take the prefetched rows, prefetch the next ones (consumed one step from now)
-        unpack_pk(pf_ip, pf_in, pf_op, pf_on, wp[(k + 2) % 3]);
-        pf_ip = load_row(A.prev, yy + 2);
-        pf_in = load_next(yy + 2);
-        pf_op = out_row(A.prev, yo + 2, false);
-        pf_on = out_row(A.next, yo + 2, true);
+        // Issue the loads of the rows the next step adds (yy + 2 and yo + 2).  They are finished (mask / permute / unpack)
+        // at the end of this step, before its flow stores: gfx9 counts loads and stores in one vmcnt and only orders
+        // returns within a type, so a wait for a load that has younger stores outstanding is a wait for those stores too.
+        const uint32_t pf_ip = fetch_row(A.prev, yy + 2), pf_op = fetch_out_prev(yo + 2);
+        const NextRaw pf_in = fetch_next(yy + 2), pf_on = fetch_out_next(yo + 2);
 
         // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
         // window only counts once its row has entered (yo >= y_first)
@@ -587,6 +600,14 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         s2 ix[4], iy[4], it[4];
         derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], mk, ix, iy, it);
         accumulate_pk(ix, iy, it, vxx, vyy, vxy, vxt, vyt);
+        // row yy - 1 is done with: its slot takes row yy + 2 once the step's arithmetic is over
+        // (the barrier keeps the scheduler from hoisting these few ALU ops -- and with them the wait -- up to the loads;
+        // pin_row keeps the sink passes from moving them down into the next step, below its loads)
+        auto take_rows = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+            pin_row(wp[k]);
+        };
 
 #else
     Row<MODE> win[3], wout[3];
@@ -634,60 +655,67 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         } else {
             accumulate<false>(ix, iy, it, ix, iy, it, vxx, vyy, vxy, vxt, vyt);
         }
+        auto take_rows = [] {};
 
 #endif
         // ---- emit output row y = yy - R ------------------------------------------------------------------------
-        if (s >= 2 * R) {
-            const int y = yy - R;
-            int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
+        // (one call site for take_rows, after the arithmetic and before the stores)
+        const bool emit = s >= 2 * R;
+        const int y = yy - R;
+        const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
+        const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
+        int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
+        float uv[8];
+        if (emit) {
             hbox4<R>(vxx, hxx);
             hbox4<R>(vyy, hyy);
             hbox4<R>(vxy, hxy);
             hbox4<R>(vxt, hxt);
             hbox4<R>(vyt, hyt);
-            const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
-            if (out_lane) {
-                const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
+            if constexpr (!SUMS) {
+                // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
+#pragma unroll
+                for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
+            }
+        }
+        take_rows();
+        if (emit && out_lane) {
+            if constexpr (SUMS) {
                 const size_t pix = rowpix + (uint32_t)cb;
-                if constexpr (SUMS) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {
+                    if (cb + j < A.w) {
+                        A.sums[pix + j] = hxx[j];
+                        A.sums[A.sums_plane + pix + j] = hyy[j];
+                        A.sums[2 * A.sums_plane + pix + j] = hxy[j];
+                        A.sums[3 * A.sums_plane + pix + j] = hxt[j];
+                        A.sums[4 * A.sums_plane + pix + j] = hyt[j];
+                    }
+                }
+            } else {
+                float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
+                if (A.accumulate) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
                         if (cb + j < A.w) {
-                            A.sums[pix + j] = hxx[j];
-                            A.sums[A.sums_plane + pix + j] = hyy[j];
-                            A.sums[2 * A.sums_plane + pix + j] = hxy[j];
-                            A.sums[3 * A.sums_plane + pix + j] = hxt[j];
-                            A.sums[4 * A.sums_plane + pix + j] = hyt[j];
+                            uv[2 * j] = dst[2 * j] + uv[2 * j];
+                            uv[2 * j + 1] = dst[2 * j + 1] + uv[2 * j + 1];
                         }
-                    }
+                }
+                if (cb + 3 < A.w) {
+                    // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
+                    float2 *d2 = reinterpret_cast<float2 *>(dst);
+                    d2[0] = make_float2(uv[0], uv[1]);
+                    d2[1] = make_float2(uv[2], uv[3]);
+                    d2[2] = make_float2(uv[4], uv[5]);
+                    d2[3] = make_float2(uv[6], uv[7]);
                 } else {
-                    float uv[8];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
-                    float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
-                    if (A.accumulate) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (cb + j < A.w) {
-                                uv[2 * j] = dst[2 * j] + uv[2 * j];
-                                uv[2 * j + 1] = dst[2 * j + 1] + uv[2 * j + 1];
-                            }
-                    }
-                    if (cb + 3 < A.w) {
-                        // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
-                        float2 *d2 = reinterpret_cast<float2 *>(dst);
-                        d2[0] = make_float2(uv[0], uv[1]);
-                        d2[1] = make_float2(uv[2], uv[3]);
-                        d2[2] = make_float2(uv[4], uv[5]);
-                        d2[3] = make_float2(uv[6], uv[7]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (cb + j < A.w) {
-                                dst[2 * j] = uv[2 * j];
-                                dst[2 * j + 1] = uv[2 * j + 1];
-                            }
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (cb + j < A.w) {
+                            dst[2 * j] = uv[2 * j];
+                            dst[2 * j + 1] = uv[2 * j + 1];
+                        }
                 }
             }
         }
