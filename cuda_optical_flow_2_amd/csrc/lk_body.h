@@ -29,6 +29,43 @@ struct LkTable {
     int n;
 };
 
+// Global-memory accessors.  The level's pointers pass through pin_scalar (below), after which the compiler no longer
+// knows they came from the kernarg segment and would fall back to flat_* instructions with 64-bit VALU address
+// arithmetic; these casts put them back into the global address space (scalar base + 32-bit lane offset).
+#define OFX_GLOBAL __attribute__((address_space(1)))
+struct __attribute__((packed)) UnalignedU32 {
+    uint32_t v;
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// (base: wave-uniform pointer; off: per-lane unsigned byte / element offset -- the cast is applied to the base so that
+// the access selects as "SGPR base + 32-bit VGPR offset"; the offset is made opaque at the access because instruction
+// selection only forms that addressing mode when the 32->64-bit extension sits in the same block as the access, and
+// loop-invariant code motion would otherwise hoist it out of the march)
+__device__ __forceinline__ uint32_t lane_off(uint32_t off)
+{
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ uint32_t gload_u32(const uint8_t *base, uint32_t off)
+{
+    return *(const OFX_GLOBAL uint32_t *)((const OFX_GLOBAL uint8_t *)base + lane_off(off));
+}
+__device__ __forceinline__ uint32_t gload_u32_unaligned(const uint8_t *base, uint32_t off)
+{
+    return ((const OFX_GLOBAL UnalignedU32 *)((const OFX_GLOBAL uint8_t *)base + lane_off(off)))->v;
+}
+typedef OFX_GLOBAL float *gfloat_ptr;
+__device__ __forceinline__ gfloat_ptr gptr_f32(float *base, uint32_t idx) { return (gfloat_ptr)base + lane_off(idx); }
+__device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b) { *(OFX_GLOBAL f32x2 *)p = f32x2{a, b}; }
+__device__ __forceinline__ void gstore_i32(int32_t *p, int32_t v) { *(OFX_GLOBAL int32_t *)p = v; }
+
+// a wave-uniform value, made opaque in an SGPR (no instruction is emitted)
+template <typename T>
+__device__ __forceinline__ void pin_scalar(T &x)
+{
+    asm volatile("" : "+s"(x));
+}
+
 // value of x held by lane (lane + D); 0 where that lane does not exist.  gfx9 DPP whole-wave shifts.
 // One whole-wave shift by a single lane.  The empty asm makes the moved value opaque so that hipcc's DPP combiner
 // cannot fold the move into its consumer: with ROCm 7.2 the folded form (v_subrev_u32_dpp) gave results shifted by
@@ -441,7 +478,23 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     if (wave >= T.first_block[T.n]) return;
     int level = 0;
     while (level + 1 < T.n && wave >= T.first_block[level + 1]) ++level;
-    const LkArgs &A = T.lv[level];
+    // The level's arguments, held in SGPRs for the whole march: left as references into the kernarg table the compiler
+    // re-reads them from memory inside the loop (~25 s_load + wait per step).
+    LkArgs A = T.lv[level];
+    pin_scalar(A.prev);
+    pin_scalar(A.next);
+    pin_scalar(A.flow);
+    pin_scalar(A.w);
+    pin_scalar(A.h);
+    pin_scalar(A.pitch);
+    pin_scalar(A.row0);
+    pin_scalar(A.row_end);
+    pin_scalar(A.flow_row0);
+    pin_scalar(A.accumulate);
+    if constexpr (SUMS) {
+        pin_scalar(A.sums);
+        pin_scalar(A.sums_plane);
+    }
     const int block = wave - T.first_block[level];
     const int tile = block % A.tiles_x;
     const int strip = block / A.tiles_x;
@@ -471,8 +524,9 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     auto fetch_row = [&](const uint8_t *img, int y) -> uint32_t {
         uint32_t v = 0u;
         if (y >= y_min && y < y_lim) {
-            const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch; // scalar
-            v = *reinterpret_cast<const uint32_t *>(row + col_off);
+            const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
+            pin_scalar(row); // scalar base + 32-bit lane offset: no VALU address arithmetic
+            v = gload_u32(row, col_off);
         }
         return v;
     };
@@ -534,12 +588,14 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
             r.have = have ? ~0u : 0u;
             if (have) {
                 const uint8_t *srow = A.next + (size_t)(uint32_t)(ny - A.row0) * (size_t)(uint32_t)A.pitch;
-                __builtin_memcpy(&r.sh, srow + nb_off, 4); // unaligned dword
+                pin_scalar(srow);
+                r.sh = gload_u32_unaligned(srow, nb_off);
             }
             // interior tile with its target row inside the image: every byte comes from the shifted dword
             if (!(have && all_in) && y < y_none) {
                 const uint8_t *orow = A.next + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
-                r.own = *reinterpret_cast<const uint32_t *>(orow + col_off);
+                pin_scalar(orow);
+                r.own = gload_u32(orow, col_off);
                 if (y == y_part) {
                     uint32_t km = 0u;
 #pragma unroll
@@ -685,15 +741,17 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (cb + j < A.w) {
-                        A.sums[pix + j] = hxx[j];
-                        A.sums[A.sums_plane + pix + j] = hyy[j];
-                        A.sums[2 * A.sums_plane + pix + j] = hxy[j];
-                        A.sums[3 * A.sums_plane + pix + j] = hxt[j];
-                        A.sums[4 * A.sums_plane + pix + j] = hyt[j];
+                        gstore_i32(A.sums + pix + j, hxx[j]);
+                        gstore_i32(A.sums + A.sums_plane + pix + j, hyy[j]);
+                        gstore_i32(A.sums + 2 * A.sums_plane + pix + j, hxy[j]);
+                        gstore_i32(A.sums + 3 * A.sums_plane + pix + j, hxt[j]);
+                        gstore_i32(A.sums + 4 * A.sums_plane + pix + j, hyt[j]);
                     }
                 }
             } else {
-                float *dst = (A.flow + 2 * rowpix) + 2u * (uint32_t)cb;
+                float *frow = A.flow + 2 * rowpix;
+                pin_scalar(frow);
+                const gfloat_ptr dst = gptr_f32(frow, 2u * (uint32_t)cb);
                 if (A.accumulate) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -704,11 +762,10 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
                 }
                 if (cb + 3 < A.w) {
                     // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
-                    float2 *d2 = reinterpret_cast<float2 *>(dst);
-                    d2[0] = make_float2(uv[0], uv[1]);
-                    d2[1] = make_float2(uv[2], uv[3]);
-                    d2[2] = make_float2(uv[4], uv[5]);
-                    d2[3] = make_float2(uv[6], uv[7]);
+                    gstore_f32x2(dst, uv[0], uv[1]);
+                    gstore_f32x2(dst + 2, uv[2], uv[3]);
+                    gstore_f32x2(dst + 4, uv[4], uv[5]);
+                    gstore_f32x2(dst + 6, uv[6], uv[7]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)

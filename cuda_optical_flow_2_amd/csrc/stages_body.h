@@ -65,6 +65,56 @@ __device__ __forceinline__ void downsample_rows(const DownArgs &A, int c4 /* gro
     *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.dst_row0) * (size_t)A.dst_pitch + x0) = out;
 }
 
+// Two vertically adjacent groups of 4 destination pixels (rows y and y+1, x0 a multiple of 4) from ONE set of loads:
+// source rows 2y-1 .. 2y+3, columns 2*x0-1 .. 2*x0+7 of a full-height source (rows [0,sh), columns [0,sw)).  All 15 loads
+// are issued before the first use.  The arithmetic is SWAR on 16-bit halves: a dword's even bytes (b0,b2) and odd bytes
+// (b1,b3) are summed down the 3 rows ([1 2 1], at most 1020), then out = left + 2*centre + right (at most 4080) >> 4:
+// the same integers as down4.
+__device__ __forceinline__ void down4x2(const uint8_t *src, int src_pitch, int sh, int sw, int dw, int dh, int x0, int y, uint32_t &out0,
+                                        uint32_t &out1)
+{
+    const int sx = 2 * x0; // multiple of 8
+    uint32_t lo[5], hi[5], lf[5];
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const int sy = 2 * y - 1 + p;
+        lo[p] = hi[p] = lf[p] = 0u;
+        if (sy >= 0 && sy < sh) {
+            const uint8_t *row = src + (size_t)sy * (size_t)src_pitch;
+            // the source pitch is a multiple of 4 and >= sw, so a dword starting below sw stays inside the row pitch
+            if (sx < sw) lo[p] = *reinterpret_cast<const uint32_t *>(row + sx);
+            if (sx + 4 < sw) hi[p] = *reinterpret_cast<const uint32_t *>(row + sx + 4);
+            if (sx > 0 && sx - 1 < sw) lf[p] = row[sx - 1];
+        }
+    }
+    // bytes at columns >= sw (pitch padding) do not count
+    const uint32_t mlo = sx + 4 <= sw ? 0xffffffffu : (sx < sw ? 0xffffffffu >> (8 * (sx + 4 - sw)) : 0u);
+    const uint32_t mhi = sx + 8 <= sw ? 0xffffffffu : (sx + 4 < sw ? 0xffffffffu >> (8 * (sx + 8 - sw)) : 0u);
+    uint32_t out[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0, left = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int p = 2 * r + t;
+            const uint32_t wgt = t == 1 ? 2u : 1u;
+            const uint32_t l = lo[p] & mlo, h = hi[p] & mhi;
+            elo += wgt * (l & 0x00ff00ffu);
+            olo += wgt * ((l >> 8) & 0x00ff00ffu);
+            ehi += wgt * (h & 0x00ff00ffu);
+            ohi += wgt * ((h >> 8) & 0x00ff00ffu);
+            left += wgt * lf[p];
+        }
+        const uint32_t a = 2u * elo + olo + ((olo << 16) | left);         // destination pixels 0 (low half) and 1
+        const uint32_t b = 2u * ehi + ohi + ((olo >> 16) | (ohi << 16));  // destination pixels 2 and 3
+        uint32_t v = ((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8) | (((b >> 4) & 0xffu) << 16) | (((b >> 20) & 0xffu) << 24);
+        if (x0 + 4 > dw) v &= x0 < dw ? 0xffffffffu >> (8 * (x0 + 4 - dw)) : 0u; // pitch padding is written as zero
+        out[r] = (y + r >= 0 && y + r < dh) ? v : 0u;
+    }
+    out0 = out[0];
+    out1 = out[1];
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Whole pyramid in ONE launch.  A 256-thread workgroup takes a 64x64 tile of level 0 and produces its part of every
 // coarser level, keeping the intermediate levels in LDS.  The 3x3 stencil at stride 2 reads source columns 2x-1..2x+1,
@@ -94,20 +144,72 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
     const int H0 = (1 << A.n) - 1;
 
     // optional: keep a copy of the level-0 tile next to the levels built from it (the stream pipeline reads the
-    // caller's frame only in the launch that receives it)
-    if (A.dst[0] != nullptr) {
-        constexpr int dw_per_row = kPyrTile / 4;
-        for (int i = tid; i < dw_per_row * kPyrTile; i += kPyrThreads) {
-            const int y = Y0 + i / dw_per_row, x = X0 + 4 * (i % dw_per_row);
-            if (y < A.h[0] && x < A.w[0]) {
-                uint32_t d = *reinterpret_cast<const uint32_t *>(A.src + (size_t)y * (size_t)A.pitch[0] + x);
-                if (x + 3 >= A.w[0]) d &= 0xffffffffu >> (8 * (x + 4 - A.w[0])); // padding bytes stay zero
-                *reinterpret_cast<uint32_t *>(A.dst[0] + (size_t)y * (size_t)A.dst0_pitch + x) = d;
+    // caller's frame only in the launch that receives it).  One 16-byte piece per thread; the load is issued here and
+    // stored after the level-1 stage so that it rides along with that stage's loads.
+    uint32_t cp[4] = {0u, 0u, 0u, 0u};
+    const int cy = Y0 + (tid >> 2), cx = X0 + 16 * (tid & 3);
+    const bool cp_any = A.dst[0] != nullptr && cy < A.h[0] && cx < A.w[0];
+    const bool cp_full = cp_any && cx + 16 <= A.w[0];
+    if (cp_full) {
+        __builtin_memcpy(cp, A.src + (size_t)cy * (size_t)A.pitch[0] + cx, 16); // 4-byte aligned
+    } else if (cp_any) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = cx + 4 * j;
+            if (x < A.w[0]) {
+                cp[j] = *reinterpret_cast<const uint32_t *>(A.src + (size_t)cy * (size_t)A.pitch[0] + x);
+                if (x + 3 >= A.w[0]) cp[j] &= 0xffffffffu >> (8 * (x + 4 - A.w[0])); // padding bytes stay zero
             }
         }
     }
 
-    for (int k = 0; k < A.n; ++k) {
+    // ---- level 1 straight from HBM (the bulk of the work: no LDS staging of level 0) -----------------------------------------
+    // a thread produces 4 horizontally adjacent pixels (global x a multiple of 4) of two rows from one set of loads
+    {
+        const int Hn = H0 >> 1, Tn = kPyrTile >> 1, Xn = X0 >> 1, Yn = Y0 >> 1;
+        uint8_t *dstr = lds + A.lds_off[1];
+        const int ds = A.stride[1];
+        const int rn = Tn + Hn;
+        const int hq = (Hn + 3) & ~3, groups = (Tn + hq + 3) / 4;
+        const int pairs = (rn + 1) / 2;
+        for (int i = tid; i < groups * pairs; i += kPyrThreads) {
+            const int ry = 2 * (i / groups), g = i % groups;
+            const int y = Yn - Hn + ry, xb = Xn - hq + 4 * g; // global coordinates at level 1
+            uint32_t pk[2] = {0u, 0u};
+            if (xb >= 0 && xb < A.w[1] && y + 1 >= 0 && y < A.h[1]) down4x2(A.src, A.pitch[0], A.h[0], A.w[0], A.w[1], A.h[1], xb, y, pk[0], pk[1]);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                if (ry + r >= rn) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rx = xb + q - (Xn - Hn);
+                    if (rx >= 0 && rx < rn) dstr[(ry + r) * ds + rx] = (uint8_t)(pk[r] >> (8 * q));
+                }
+                // the tile's own part (not the halo) goes to HBM
+                if (ry + r >= Hn && y + r < A.h[1] && xb >= Xn && xb < A.w[1]) {
+                    uint8_t *row = A.dst[1] + (size_t)(y + r) * (size_t)A.pitch[1];
+                    if (xb + 3 < Xn + Tn && xb + 3 < A.w[1]) {
+                        *reinterpret_cast<uint32_t *>(row + xb) = pk[r];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (xb + q < Xn + Tn && xb + q < A.w[1]) row[xb + q] = (uint8_t)(pk[r] >> (8 * q));
+                    }
+                }
+            }
+        }
+    }
+    if (cp_full) {
+        __builtin_memcpy(A.dst[0] + (size_t)cy * (size_t)A.dst0_pitch + cx, cp, 16);
+    } else if (cp_any) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (cx + 4 * j < A.w[0]) *reinterpret_cast<uint32_t *>(A.dst[0] + (size_t)cy * (size_t)A.dst0_pitch + cx + 4 * j) = cp[j];
+    }
+    __syncthreads();
+
+    // ---- deeper levels from LDS --------------------------------------------------------------------------------------
+    for (int k = 1; k < A.n; ++k) {
         // level k region origin O_k = X_k - H_k (size T_k + H_k); O_k = 2*O_{k+1} - 1, so the taps 2x-1..2x+1 of the
         // level-(k+1) pixel at region column rx are the level-k region columns 2*rx .. 2*rx+2
         const int Hn = H0 >> (k + 1), Tn = kPyrTile >> (k + 1), Xn = X0 >> (k + 1), Yn = Y0 >> (k + 1);
@@ -121,32 +223,21 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
             const int ry = i / groups, g = i % groups;
             const int y = Yn - Hn + ry, xb = Xn - hq + 4 * g; // global coordinates at level k+1
             uint32_t packed = 0;
-            if (k == 0) {
-                // level 1 comes straight from HBM with aligned dword reads (the bulk of the work: no LDS staging of level 0)
-                if (y >= 0 && y < A.h[1] && xb >= 0 && xb < A.w[1])
-                    packed = down4(A.src, A.pitch[0], 0, 0, A.h[0], A.w[0], A.w[1], xb, y);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rx = xb + q - (Xn - Hn);
-                    if (rx >= 0 && rx < rn) dstr[ry * ds + rx] = (uint8_t)(packed >> (8 * q));
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int x = xb + q, rx = x - (Xn - Hn);
-                    int v = 0;
-                    if (rx >= 0 && rx < rn) {
-                        if (x >= 0 && y >= 0 && x < A.w[k + 1] && y < A.h[k + 1]) {
-                            const uint8_t *p = srcr + (2 * ry) * ss + 2 * rx;
-                            const int c0 = p[0] + 2 * p[ss] + p[2 * ss];
-                            const int c1 = p[1] + 2 * p[ss + 1] + p[2 * ss + 1];
-                            const int c2 = p[2] + 2 * p[ss + 2] + p[2 * ss + 2];
-                            v = (c0 + 2 * c1 + c2) >> 4;
-                        }
-                        dstr[ry * ds + rx] = (uint8_t)v;
+            for (int q = 0; q < 4; ++q) {
+                const int x = xb + q, rx = x - (Xn - Hn);
+                int v = 0;
+                if (rx >= 0 && rx < rn) {
+                    if (x >= 0 && y >= 0 && x < A.w[k + 1] && y < A.h[k + 1]) {
+                        const uint8_t *p = srcr + (2 * ry) * ss + 2 * rx;
+                        const int c0 = p[0] + 2 * p[ss] + p[2 * ss];
+                        const int c1 = p[1] + 2 * p[ss + 1] + p[2 * ss + 1];
+                        const int c2 = p[2] + 2 * p[ss + 2] + p[2 * ss + 2];
+                        v = (c0 + 2 * c1 + c2) >> 4;
                     }
-                    packed |= (uint32_t)v << (8 * q);
+                    dstr[ry * ds + rx] = (uint8_t)v;
                 }
+                packed |= (uint32_t)v << (8 * q);
             }
             // the tile's own part (not the halo) goes to HBM
             if (ry >= Hn && y < A.h[k + 1] && xb >= Xn && xb < A.w[k + 1]) {
