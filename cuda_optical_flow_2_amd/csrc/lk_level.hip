@@ -51,13 +51,17 @@ struct StreamArgs {
     PyrArgs pyr;
     CornerArgs corner;
     // block 0 = corner wave; [1, pyr_first) LK (four waves per block); [pyr_first, sh_first) pyramid; [sh_first, end) shift.
-    // The LK blocks come first and are sized to ~85% of the resident-wave capacity: they all start at once and run for the
+    // The LK blocks come first and are planned for 3 waves per SIMD (lk_wave_target): they all start at once and run for the
     // whole launch, while the short staging blocks stream through the remaining slots underneath them.
     int pyr_first, pyr_blocks_x, sh_first;
 };
 
+// lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu would spill there
+#ifndef OFX_STREAM_MIN_BLOCKS
+#define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 3)
+#endif
 template <int R, int MODE>
-__global__ __launch_bounds__(256, 3) void stream_kernel(const StreamArgs S)
+__global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -120,21 +124,30 @@ int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
     return blocks;
 }
 
+// Number of LK waves a launch is planned for.  Every LK wave runs for the whole launch, so what matters is how many of
+// them share a SIMD: measured on MI355X (4K, 9x9) 3 per SIMD is the optimum once the march no longer waits on its own
+// loads -- fewer leave issue slots empty, more shorten the strips (each strip pays 2R priming rows) -- and a count that
+// is not a whole number per SIMD makes the fuller SIMDs set the time.  `reserve` slots per SIMD are left to the other
+// stages of the stream kernel.
 template <typename K>
-int resident_waves(K kernel, int threads, size_t lds)
+int lk_wave_target(K kernel, int threads, size_t lds, int reserve)
 {
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu <= 0) per_cu = 8 * 64 / threads;
     (void)hipGetLastError();
-    return env_int("OFX_LK_TARGET_WAVES", cus * per_cu * (threads / 64));
+    const int occ = per_cu * (threads / 64) / 4; // waves per SIMD (4 SIMDs per CU)
+    int per_simd = env_int("OFX_LK_WAVES_PER_SIMD", 3);
+    if (per_simd > occ - reserve) per_simd = occ - reserve;
+    if (per_simd < 1) per_simd = 1;
+    return env_int("OFX_LK_TARGET_WAVES", cus * 4 * per_simd);
 }
 
 template <int R, int MODE, bool SUMS>
 int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = resident_waves(lk_level_kernel<R, MODE, SUMS>, 64, 0);
+    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS>, 64, 0, 0);
     LkTable t{};
     const int blocks = plan_table<R>(lv, n, capacity, &t);
     hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3((unsigned)blocks), dim3(64), 0, st, t);
@@ -145,7 +158,7 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 template <int R, int MODE>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, int sh_blocks, size_t lds, hipStream_t st)
 {
-    static const int capacity = resident_waves(stream_kernel<R, MODE>, 256, 16 * 1024) * env_int("OFX_STREAM_LK_PERCENT", 85) / 100;
+    static const int capacity = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1);
     int lk_blocks = 0;
     if (n > 0) lk_blocks = ofx_div_up(plan_table<R>(lv, n, capacity, &S.lk), 4);
     S.pyr_first = 1 + lk_blocks;
