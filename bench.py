@@ -110,7 +110,7 @@ def main():
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
-            # one launch per frame: pyramid(frame j) | corner(pair j-1) | shifts(pair j-2) | LK(pair j-3) side by side in
+            # one launch per frame: pyramid(frame j) | corner(pair j-1) | fused LK(pair j-2, global shift in its loads) side by side in
             # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
             sess.stream_begin()
             for i in range(3):
@@ -188,7 +188,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload)
+                # per workload: {"stream_kernel": bytes, "lk_level_kernel": bytes} (tools/pmc_parse.py on separate --pmc passes)
+                t = json.load(open(tpath)).get(args.workload)
+                kname = "stream_kernel" if driver is None and args.path == "stream" else "lk_level_kernel"
+                traffic = t.get(kname) if isinstance(t, dict) else None
             except Exception:
                 traffic = None
         out = {

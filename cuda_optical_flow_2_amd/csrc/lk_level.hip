@@ -41,8 +41,9 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
 // Launch j of a frame stream runs, as disjoint block ranges of ONE grid,
-//     pyramid(frame j)  |  corner flows(pair j-1)  |  shifts(pair j-2)  |  fused LK(pair j-3)
-// Each stage consumes what launch j-1 wrote, so there is no synchronisation inside the launch and none between streams;
+//     pyramid(frame j)  |  corner flows(pair j-1)  |  fused LK(pair j-2)
+// (a stand-alone shift stage can be scheduled as a fourth range; the session does not use it since the shift moved into
+// the LK loads).  Each stage consumes what launch j-1 wrote, so there is no synchronisation inside the launch and none between streams;
 // the small latency-bound stages run in the shadow of the VALU-bound LK stage.  Blocks are 256 threads; an LK block is
 // four independent LK waves.
 struct StreamArgs {
