@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
+                    help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
+                         "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
     args = ap.parse_args()
 
     import numpy as np
@@ -95,7 +98,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its communicator is created; stdout carries only the JSON line, so
+        # the banner is sent to stderr (fd-level: it comes from the C library)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     w, h, levels, window = WORKLOADS[args.workload]
     # a short ring of resident frames: a smooth texture translating by (2,1) px per frame
@@ -134,12 +149,23 @@ def main():
     else:
         from cuda_optical_flow_2_amd import parallel
 
-        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank)
+        # One pair row-sharded over the ranks (strong scaling).  Default: every rank runs the one-launch-per-frame stream
+        # pipeline on its row block with the corner flows computed from its own top-left patch -- no collective on the data
+        # path; --shard-corner broadcast keeps rank 0's corner kernel + one RCCL broadcast per pair (staged halves).
+        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner)
         sess = driver.session
-        driver.push_frame(d_frames[0])
+        if args.shard_corner == "local":
+            driver.stream_begin()
+            for i in range(3):
+                driver.stream_submit(d_frames[i % nframes])
 
-        def step(i):
-            driver.step(d_frames[(i + 1) % nframes])
+            def step(i):
+                driver.stream_submit(d_frames[i % nframes])
+        else:
+            driver.push_frame(d_frames[0])
+
+            def step(i):
+                driver.step(d_frames[(i + 1) % nframes])
 
     def fence():
         torch.cuda.synchronize()
@@ -180,9 +206,12 @@ def main():
         if args.iters > 1:
             # every LK launch is timed: the first writes the flow (10 B/px), the others also read it back (18 B/px)
             lk_bytes = (10 + (args.iters - 1) * 18) * own_px // args.iters
-        if driver is None and args.path == "stream":
+        sharded_stream = driver is not None and args.shard_corner == "local"
+        if (driver is None and args.path == "stream") or sharded_stream:
             # the stream launch also builds the next frame's pyramid: + 5 B per destination pixel of levels 1..
-            lk_bytes += 5 * sum((w >> k) * (h >> k) for k in range(1, levels))
+            # (a rank of a sharded run builds the rows it owns)
+            lk_bytes += 5 * sum((w >> k) * ((h >> k) if driver is None else (driver.plan.own[k][1] - driver.plan.own[k][0]))
+                                for k in range(1, levels))
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -191,7 +220,7 @@ def main():
                 # per workload: {"stream_kernel": bytes, "lk_level_kernel": bytes} (tools/pmc_parse.py on separate --pmc passes)
                 t = json.load(open(tpath)).get(args.workload)
                 kname = "stream_kernel" if driver is None and args.path == "stream" else "lk_level_kernel"
-                traffic = t.get(kname) if isinstance(t, dict) else None
+                traffic = t.get(kname) if isinstance(t, dict) and driver is None else None  # measured for whole frames only
             except Exception:
                 traffic = None
         out = {
@@ -210,13 +239,16 @@ def main():
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
-                "sharding": "none" if driver is None else f"row blocks over {world} rank(s): halos recomputed from a wider level-0 halo, "
-                            "one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)",
+                "sharding": "none" if driver is None else (
+                    f"row blocks over {world} rank(s), halos recomputed from a wider level-0 halo; " +
+                    ("every rank runs the one-launch stream pipeline on its block and forms the shift vectors from its own top-left "
+                     "patch of the frame: no collective on the data path (DESIGN.md section 5)" if sharded_stream else
+                     "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)")),
             },
             "roofline": {
                 "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels for pair j-2 | corner flows of pair j-1 | pyramid of "
                             "frame j; bytes = 10 B/px LK + 5 B/px pyramid)"
-                           if driver is None and args.path == "stream" else
+                           if (driver is None and args.path == "stream") or sharded_stream else
                            "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),

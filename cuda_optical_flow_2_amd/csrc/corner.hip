@@ -22,7 +22,8 @@ __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
 
 } // namespace
 
-int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, CornerArgs *out)
+int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
+                    CornerArgs *out)
 {
     OFX_REQUIRE(levels && d_uv && n_levels >= 1 && n_levels <= OFX_MAX_LEVELS, "ofx_corner_flows: bad arguments");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_corner_flows: window must be odd and >= 3 (got %d)", window);
@@ -31,14 +32,20 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
     a.levels = n_levels;
     a.radius = window >> 1;
     a.uv = d_uv;
+    a.status = d_status;
     for (int k = 0; k < n_levels; ++k) {
         const ofx_geom *g = &levels[k].geom;
-        OFX_TRY(ofx_check_geom(g, "ofx_corner_flows"));
+        ofx_geom gc = *g; // a patch's planes are cols[k] wide: that is what the pitch has to cover
+        if (cols && cols[k] > 0 && cols[k] < g->w) gc.w = cols[k];
+        OFX_TRY(ofx_check_geom(&gc, "ofx_corner_flows"));
         OFX_REQUIRE(levels[k].d_prev && levels[k].d_next, "ofx_corner_flows: null plane at level %d", k);
         OFX_REQUIRE(g->row0 == 0, "ofx_corner_flows: level %d buffer must start at row 0 (it holds rows from %d)", k, g->row0);
         const int need = a.radius + 2 < g->h ? a.radius + 2 : g->h;
         OFX_REQUIRE(g->rows >= need, "ofx_corner_flows: level %d holds %d rows, the corner needs %d", k, g->rows, need);
-        a.lv[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0};
+        const int col_end = cols && cols[k] > 0 ? cols[k] : g->w;
+        OFX_REQUIRE(col_end <= g->pitch && col_end >= (a.radius + 2 < g->w ? a.radius + 2 : g->w),
+                    "ofx_corner_flows: level %d holds %d columns, the corner needs %d", k, col_end, a.radius + 2);
+        a.lv[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0, col_end};
     }
     *out = a;
     return OFX_OK;
@@ -47,7 +54,7 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
 extern "C" int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, void *stream)
 {
     CornerArgs a{};
-    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, &a));
+    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, &a));
     if (mode == OFX_MODE_LK_FLOAT)
         hipLaunchKernelGGL(corner_kernel<OFX_MODE_LK_FLOAT>, dim3(1), dim3(64), 0, ofx_stream(stream), a);
     else

@@ -51,10 +51,12 @@ struct StreamArgs {
     ShiftTable sh;
     PyrArgs pyr;
     CornerArgs corner;
-    // block 0 = corner wave; [1, pyr_first) LK (four waves per block); [pyr_first, sh_first) pyramid; [sh_first, end) shift.
+    PyrArgs patch; // pyramid of the frame's top-left patch (sharded sessions: local corner flows)
+    // block 0 = corner wave; [1, pyr_first) LK (four waves per block); [pyr_first, patch_first) pyramid;
+    // [patch_first, sh_first) patch pyramid; [sh_first, end) shift.
     // The LK blocks come first and are planned for 3 waves per SIMD (lk_wave_target): they all start at once and run for the
     // whole launch, while the short staging blocks stream through the remaining slots underneath them.
-    int pyr_first, pyr_blocks_x, sh_first;
+    int pyr_first, pyr_blocks_x, patch_first, patch_blocks_x, sh_first;
 };
 
 // lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu would spill there
@@ -73,9 +75,12 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // counters) must live in SGPRs as it does in the stand-alone kernel
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         lk_wave<R, MODE, false>(S.lk, 4 * (b - 1) + wv, tid & 63);
-    } else if (b < S.sh_first) {
+    } else if (b < S.patch_first) {
         const int pb = b - S.pyr_first;
-        pyramid_block(S.pyr, pb % S.pyr_blocks_x, pb / S.pyr_blocks_x, tid, lds);
+        pyramid_block(S.pyr, pb % S.pyr_blocks_x, pb / S.pyr_blocks_x + S.pyr.by0, tid, lds);
+    } else if (b < S.sh_first) {
+        const int pb = b - S.patch_first;
+        pyramid_block(S.patch, pb % S.patch_blocks_x, pb / S.patch_blocks_x, tid, lds);
     } else {
         shift_block(S.sh, b - S.sh_first, tid);
     }
@@ -157,13 +162,14 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 }
 
 template <int R, int MODE>
-int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, int sh_blocks, size_t lds, hipStream_t st)
+int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, int patch_blocks, int sh_blocks, size_t lds, hipStream_t st)
 {
     static const int capacity = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1);
     int lk_blocks = 0;
     if (n > 0) lk_blocks = ofx_div_up(plan_table<R>(lv, n, capacity, &S.lk), 4);
     S.pyr_first = 1 + lk_blocks;
-    S.sh_first = S.pyr_first + pyr_blocks;
+    S.patch_first = S.pyr_first + pyr_blocks;
+    S.sh_first = S.patch_first + patch_blocks;
     const int blocks = S.sh_first + sh_blocks;
     if (lds < 2 * OFX_MAX_LEVELS * sizeof(float)) lds = 2 * OFX_MAX_LEVELS * sizeof(float); // the corner wave's scratch
     hipLaunchKernelGGL((stream_kernel<R, MODE>), dim3((unsigned)blocks), dim3(256), lds, st, S);
@@ -172,24 +178,24 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, i
 }
 
 template <int MODE>
-int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, int pb, int sb, size_t lds, hipStream_t st)
+int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, int pb, int qb, int sb, size_t lds, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_stream_r<1, MODE>(lv, n, S, pb, sb, lds, st);
-    case 2: return launch_stream_r<2, MODE>(lv, n, S, pb, sb, lds, st);
-    case 3: return launch_stream_r<3, MODE>(lv, n, S, pb, sb, lds, st);
-    case 4: return launch_stream_r<4, MODE>(lv, n, S, pb, sb, lds, st);
-    case 5: return launch_stream_r<5, MODE>(lv, n, S, pb, sb, lds, st);
-    case 6: return launch_stream_r<6, MODE>(lv, n, S, pb, sb, lds, st);
-    case 7: return launch_stream_r<7, MODE>(lv, n, S, pb, sb, lds, st);
-    case 8: return launch_stream_r<8, MODE>(lv, n, S, pb, sb, lds, st);
-    case 9: return launch_stream_r<9, MODE>(lv, n, S, pb, sb, lds, st);
-    case 10: return launch_stream_r<10, MODE>(lv, n, S, pb, sb, lds, st);
-    case 11: return launch_stream_r<11, MODE>(lv, n, S, pb, sb, lds, st);
+    case 1: return launch_stream_r<1, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 2: return launch_stream_r<2, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 3: return launch_stream_r<3, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 4: return launch_stream_r<4, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 5: return launch_stream_r<5, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 6: return launch_stream_r<6, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 7: return launch_stream_r<7, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 8: return launch_stream_r<8, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 9: return launch_stream_r<9, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 10: return launch_stream_r<10, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 11: return launch_stream_r<11, MODE>(lv, n, S, pb, qb, sb, lds, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, pb, sb, lds, st);
+        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, pb, qb, sb, lds, st);
     }
     ofx_set_error("ofx_stream_launch: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
@@ -285,25 +291,40 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_stream_launch: bad mode %d", mode);
     StreamArgs S{};
     size_t lds = 0;
-    int pyr_blocks = 0, sh_blocks = 0;
+    int pyr_blocks = 0, patch_blocks = 0, sh_blocks = 0;
     if (g->pyr_levels >= 2) {
         int bx = 0, by = 0;
         OFX_TRY(ofx_pyramid_args(g->d_frame, g->frame_pitch, g->w, g->h, g->d_levels, g->pitches, g->pyr_levels, g->d_levels[0],
-                                 g->pitches[0], &S.pyr, &lds, &bx, &by));
+                                 g->pitches[0], g->pyr_windowed ? g->pyr_row0 : nullptr, g->pyr_windowed ? g->pyr_rows : nullptr, &S.pyr,
+                                 &lds, &bx, &by));
         S.pyr_blocks_x = bx;
         pyr_blocks = bx * by;
     } else {
         S.pyr_blocks_x = 1;
     }
-    if (g->corner_levels > 0) OFX_TRY(ofx_corner_args(g->corner, g->corner_levels, window, mode, g->d_uv, &S.corner));
+    S.patch_blocks_x = 1;
+    if (g->patch_levels >= 2) {
+        OFX_REQUIRE(g->pyr_levels >= 2 && g->patch_w > 0 && g->patch_h > 0 && g->patch_w <= g->w && g->patch_h <= g->h,
+                    "ofx_stream_launch: the patch pyramid needs a frame and a patch inside it");
+        int bx = 0, by = 0;
+        size_t lds2 = 0;
+        OFX_TRY(ofx_pyramid_args(g->d_frame, g->frame_pitch, g->patch_w, g->patch_h, g->d_patch_levels, g->patch_pitches, g->patch_levels,
+                                 g->d_patch_levels[0], g->patch_pitches[0], nullptr, nullptr, &S.patch, &lds2, &bx, &by));
+        S.patch_blocks_x = bx;
+        patch_blocks = bx * by;
+        lds = lds2 > lds ? lds2 : lds;
+    }
+    if (g->corner_levels > 0)
+        OFX_TRY(ofx_corner_args(g->corner, g->corner_levels, window, mode, g->d_uv, g->corner_cols, g->d_corner_status, &S.corner));
     if (g->n_shift > 0) OFX_TRY(ofx_shift_table(g->shift, g->n_shift, &S.sh, &sh_blocks));
     LkLevelIn lv[OFX_MAX_LEVELS];
     int m = 0;
     if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
-    if (pyr_blocks == 0 && sh_blocks == 0 && m == 0 && g->corner_levels <= 0) return OFX_OK;
+    if (pyr_blocks == 0 && patch_blocks == 0 && sh_blocks == 0 && m == 0 && g->corner_levels <= 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
-    return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, pyr_blocks, sh_blocks, lds, st)
-                                     : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, pyr_blocks, sh_blocks, lds, st);
+    return mode == OFX_MODE_LK_FLOAT
+               ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, pyr_blocks, patch_blocks, sh_blocks, lds, st)
+               : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, pyr_blocks, patch_blocks, sh_blocks, lds, st);
 }
 
 extern "C" int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream)

@@ -50,7 +50,11 @@ struct PyrArgs;
 struct ShiftTable;
 struct CornerArgs;
 } // namespace ofx_dev
+// row0/rows (NULL: whole levels): the global rows each destination plane (index 0 = the level-0 copy) holds
 int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
-                     uint8_t *d_level0_copy, int copy_pitch, ofx_dev::PyrArgs *out, size_t *lds_bytes, int *blocks_x, int *blocks_y);
+                     uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, ofx_dev::PyrArgs *out,
+                     size_t *lds_bytes, int *blocks_x, int *blocks_y);
 int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *out, int *blocks_out);
-int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, ofx_dev::CornerArgs *out);
+// cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerArgs::status
+int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
+                    ofx_dev::CornerArgs *out);

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void downsample_1ch_kernel(const DownArgs A)
 __global__ __launch_bounds__(kPyrThreads) void pyramid_fused_kernel(const PyrArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    pyramid_block(A, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, lds);
+    pyramid_block(A, (int)blockIdx.x, (int)blockIdx.y + A.by0, (int)threadIdx.x, lds);
 }
 
 __global__ __launch_bounds__(256) void shift_1ch_kernel(const ShiftTable T)
@@ -159,7 +159,8 @@ extern "C" int ofx_downsample_1ch(const uint8_t *d_src, int src_pitch, int src_r
 // Fills the arguments of the fused pyramid stage; returns the dynamic LDS it needs and its grid (shared with the
 // stream kernel's launcher in lk_level.hip).
 int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
-                     uint8_t *d_level0_copy, int copy_pitch, PyrArgs *out, size_t *lds_bytes, int *blocks_x, int *blocks_y)
+                     uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, PyrArgs *out, size_t *lds_bytes,
+                     int *blocks_x, int *blocks_y)
 {
     OFX_REQUIRE(d_level0 && d_levels && pitches && w > 0 && h > 0, "ofx_pyramid_1ch: bad arguments");
     OFX_REQUIRE(levels >= 2 && levels - 1 <= kPyrMaxProduced, "ofx_pyramid_1ch: %d levels unsupported (2..%d)", levels,
@@ -193,8 +194,27 @@ int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t 
     area[0] = (area[0] + 15) & ~(size_t)15;
     for (int k = 0; k <= a.n; ++k) a.lds_off[k] = (k & 1) ? (int)area[0] : 0;
     *lds_bytes = area[0] + ((area[1] + 15) & ~(size_t)15);
+    // destination row windows (row0 == NULL: whole levels).  The tiles launched are those that intersect any window,
+    // expressed in level-0 rows: a level-k row y belongs to the tile row (y << k) / kPyrTile.
+    int t0 = 0, t1 = ofx_div_up(h, kPyrTile);
+    for (int k = 0; k < levels; ++k) {
+        a.row0[k] = row0 ? row0[k] : 0;
+        a.row1[k] = row0 ? row0[k] + rows[k] : (h >> k);
+        OFX_REQUIRE(a.row0[k] >= 0 && a.row0[k] <= a.row1[k] && a.row1[k] <= (h >> k), "ofx_pyramid_1ch: bad row window at level %d", k);
+    }
+    if (row0) {
+        int lo = h, hi = 0;
+        for (int k = 0; k < levels; ++k) {
+            if (a.row1[k] <= a.row0[k]) continue;
+            lo = (a.row0[k] << k) < lo ? (a.row0[k] << k) : lo;
+            hi = (a.row1[k] << k) > hi ? (a.row1[k] << k) : hi;
+        }
+        t0 = lo / kPyrTile;
+        t1 = hi > lo ? ofx_div_up(hi, kPyrTile) : t0;
+    }
+    a.by0 = t0;
     *blocks_x = ofx_div_up(w, kPyrTile);
-    *blocks_y = ofx_div_up(h, kPyrTile);
+    *blocks_y = t1 - t0;
     *out = a;
     return OFX_OK;
 }
@@ -205,7 +225,7 @@ extern "C" int ofx_pyramid_1ch(const uint8_t *d_level0, int pitch0, int w, int h
     PyrArgs a{};
     size_t lds_bytes = 0;
     int bx = 0, by = 0;
-    OFX_TRY(ofx_pyramid_args(d_level0, pitch0, w, h, d_levels, pitches, levels, nullptr, 0, &a, &lds_bytes, &bx, &by));
+    OFX_TRY(ofx_pyramid_args(d_level0, pitch0, w, h, d_levels, pitches, levels, nullptr, 0, nullptr, nullptr, &a, &lds_bytes, &bx, &by));
     hipLaunchKernelGGL(pyramid_fused_kernel, dim3(bx, by), dim3(kPyrThreads), lds_bytes, ofx_stream(stream), a);
     OFX_HIP(hipGetLastError());
     return OFX_OK;

@@ -41,6 +41,10 @@ struct ofx_session {
     // index of the newest frame whose pyramid exists once tick f has been issued
     long stream_last_frame(long f, bool has_frame) const { return stream_frames >= 0 ? stream_frames - 1 : (has_frame ? f : f - 1); }
     int pitch0_next() const { return pitch[0]; }
+    // local_corner: the top-left patch of every frame as a pyramid of its own (same 5 sets as img)
+    uint8_t *pimg[5][OFX_MAX_LEVELS]{};
+    int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
+    int *corner_status = nullptr;
     float *flow[OFX_MAX_LEVELS]{};
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
@@ -134,6 +138,34 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         const size_t own_rows = (size_t)(s->own1[k] - s->own0[k]);
         total += align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
     }
+    std::vector<size_t> off_patch[5];
+    if (p->local_corner) {
+        const int step = 1 << (p->levels - 1);
+        int side = p->patch_size > 0 ? p->patch_size : step * ((p->window >> 1) + 2 + 8);
+        if (p->patch_size <= 0 && side < 256) side = 256;
+        side = (int)align_up((size_t)side, (size_t)step);
+        const int pw0 = side < p->width ? side : p->width, ph0 = side < p->height ? side : p->height;
+        for (int k = 0; k < p->levels; ++k) {
+            s->pw[k] = pw0 >> k;
+            s->ph[k] = ph0 >> k;
+            s->ppitch[k] = (int)align_up((size_t)s->pw[k], 64);
+            const size_t bytes = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
+            for (int t = 0; t < 5; ++t) {
+                off_patch[t].push_back(total);
+                total += bytes;
+            }
+        }
+        const int need = (p->window >> 1) + 2;
+        const int lc = p->levels - 1;
+        if (s->pw[lc] < (need < s->w[lc] ? need : s->w[lc]) || s->ph[lc] < (need < s->h[lc] ? need : s->h[lc])) {
+            ofx_set_error("ofx_session_create: patch_size %d leaves %dx%d at the coarsest level, the corner needs %d", side, s->pw[lc],
+                          s->ph[lc], need);
+            delete s;
+            return OFX_E_INVALID;
+        }
+    }
+    const size_t off_status = total;
+    total += kAlign;
     const size_t off_uv = total;
     total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * 2, kAlign); // two sets (the stream pipeline alternates)
     const size_t off_staging = total;
@@ -159,6 +191,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[5 + t][k];
         s->flow[k] = reinterpret_cast<float *>(base + off_flow[k]);
     }
+    if (p->local_corner)
+        for (int k = 0; k < p->levels; ++k)
+            for (int t = 0; t < 5; ++t) s->pimg[t][k] = base + off_patch[t][k];
+    s->corner_status = reinterpret_cast<int *>(base + off_status);
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = base + off_staging;
     repoint(s);
@@ -567,6 +603,16 @@ extern "C" int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst
     return OFX_OK;
 }
 
+extern "C" int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream)
+{
+    OFX_REQUIRE(s && h_status, "ofx_session_corner_status: null argument");
+    hipStream_t st = ofx_stream(stream);
+    OFX_HIP(hipMemcpyAsync(h_status, s->corner_status, sizeof(int), hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipMemsetAsync(s->corner_status, 0, sizeof(int), st));
+    OFX_HIP(hipStreamSynchronize(st));
+    return OFX_OK;
+}
+
 // ---- stream pipeline: one launch per frame ---------------------------------------------------------------------------
 // Frame f (0-based) submitted at tick f; tick f runs  pyramid(frame f) | corner(pair f-1) | LK(pair f-2, shift fused)
 // where pair p is (frame p-1 -> frame p).  Frame f lives in image set f mod 5 and pair p's shift vectors in slot p mod 2,
@@ -575,7 +621,9 @@ extern "C" int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst
 extern "C" int ofx_session_stream_begin(ofx_session *s)
 {
     OFX_REQUIRE(s, "ofx_session_stream_begin: null session");
-    OFX_REQUIRE(!s->p.sharded, "ofx_session_stream_begin: the stream pipeline runs whole frames; shard with the staged API");
+    OFX_REQUIRE(!s->p.sharded || s->p.local_corner,
+                "ofx_session_stream_begin: on a sharded session the stream pipeline needs local_corner (the corner flows "
+                "computed from each frame's top-left patch); otherwise drive the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
     OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
     s->stream_n = 0;
@@ -599,24 +647,44 @@ static int stream_tick(ofx_session *s, const uint8_t *d_gray1, int pitch, void *
         g.w = s->w[0];
         g.h = s->h[0];
         g.pyr_levels = L;
+        g.pyr_windowed = s->p.sharded ? 1 : 0;
         for (int k = 0; k < L; ++k) {
             g.d_levels[k] = s->img[set_of(f)][k];
             g.pitches[k] = s->pitch[k];
+            g.pyr_row0[k] = s->buf0[k];
+            g.pyr_rows[k] = s->buf1[k] - s->buf0[k];
+        }
+        if (s->p.local_corner) { // the same frame's top-left patch, as a pyramid of its own
+            g.patch_w = s->pw[0];
+            g.patch_h = s->ph[0];
+            g.patch_levels = L;
+            for (int k = 0; k < L; ++k) {
+                g.d_patch_levels[k] = s->pimg[set_of(f)][k];
+                g.patch_pitches[k] = s->ppitch[k];
+            }
         }
     }
     const long pc = f - 1; // corner(pair pc): frames pc-1 -> pc, both pyramids complete since the previous tick
     if (pc >= 1 && pc <= s->stream_last_frame(f, d_gray1 != nullptr)) {
         g.corner_levels = L;
         g.d_uv = uvset[pc & 1];
-        for (int k = 0; k < L; ++k)
-            g.corner[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr};
+        for (int k = 0; k < L; ++k) {
+            if (s->p.local_corner) {
+                ofx_geom pg{s->w[k], s->h[k], s->ppitch[k], 0, s->ph[k], 0, s->ph[k]};
+                g.corner[k] = ofx_lk_desc{s->pimg[set_of(pc - 1)][k], s->pimg[set_of(pc)][k], pg, nullptr, 0, nullptr, 0};
+                g.corner_cols[k] = s->pw[k];
+            } else {
+                g.corner[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr, 0};
+            }
+        }
+        if (s->p.local_corner) g.d_corner_status = s->corner_status;
     }
     const long pl = f - 2; // LK(pair pl), reading next through the shift vectors the previous tick's corner stage wrote
     *completed_pair = -1;
     if (pl >= 1 && pl <= s->stream_last_frame(f, d_gray1 != nullptr)) {
         for (int k = L - 1; k >= 0; --k)
-            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0,
-                                         k == L - 1 ? nullptr : uvset[pl & 1] + 2 * k};
+            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, s->own0[k], s->own1[k]),
+                                         s->flow[k], s->own0[k], k == L - 1 ? nullptr : uvset[pl & 1] + 2 * k, 0};
         *completed_pair = (int)pl;
     }
     (void)halo;

@@ -133,6 +133,10 @@ struct PyrArgs {
     int stride[kPyrMaxProduced + 1];   // LDS row stride of level k's region
     int lds_off[kPyrMaxProduced + 1];  // LDS byte offset of level k's region (levels alternate between two areas)
     int dst0_pitch;                    // pitch of the optional level-0 copy dst[0]
+    // Row window of the destination planes (sharded sessions): dst[k] holds global rows [row0[k], row1[k]) and only those
+    // are stored; the source frame is always complete.  by0 = first tile row of the grid.  Whole levels: 0 / h[k] / 0.
+    int row0[kPyrMaxProduced + 1], row1[kPyrMaxProduced + 1];
+    int by0;
 };
 
 constexpr int kPyrThreads = 256; // small workgroups: they must find room next to the LK waves of the previous pair
@@ -148,7 +152,7 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
     // stored after the level-1 stage so that it rides along with that stage's loads.
     uint32_t cp[4] = {0u, 0u, 0u, 0u};
     const int cy = Y0 + (tid >> 2), cx = X0 + 16 * (tid & 3);
-    const bool cp_any = A.dst[0] != nullptr && cy < A.h[0] && cx < A.w[0];
+    const bool cp_any = A.dst[0] != nullptr && cy >= A.row0[0] && cy < A.row1[0] && cx < A.w[0];
     const bool cp_full = cp_any && cx + 16 <= A.w[0];
     if (cp_full) {
         __builtin_memcpy(cp, A.src + (size_t)cy * (size_t)A.pitch[0] + cx, 16); // 4-byte aligned
@@ -186,8 +190,8 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
                     if (rx >= 0 && rx < rn) dstr[(ry + r) * ds + rx] = (uint8_t)(pk[r] >> (8 * q));
                 }
                 // the tile's own part (not the halo) goes to HBM
-                if (ry + r >= Hn && y + r < A.h[1] && xb >= Xn && xb < A.w[1]) {
-                    uint8_t *row = A.dst[1] + (size_t)(y + r) * (size_t)A.pitch[1];
+                if (ry + r >= Hn && y + r >= A.row0[1] && y + r < A.row1[1] && xb >= Xn && xb < A.w[1]) {
+                    uint8_t *row = A.dst[1] + (size_t)(y + r - A.row0[1]) * (size_t)A.pitch[1];
                     if (xb + 3 < Xn + Tn && xb + 3 < A.w[1]) {
                         *reinterpret_cast<uint32_t *>(row + xb) = pk[r];
                     } else {
@@ -200,11 +204,12 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
         }
     }
     if (cp_full) {
-        __builtin_memcpy(A.dst[0] + (size_t)cy * (size_t)A.dst0_pitch + cx, cp, 16);
+        __builtin_memcpy(A.dst[0] + (size_t)(cy - A.row0[0]) * (size_t)A.dst0_pitch + cx, cp, 16);
     } else if (cp_any) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (cx + 4 * j < A.w[0]) *reinterpret_cast<uint32_t *>(A.dst[0] + (size_t)cy * (size_t)A.dst0_pitch + cx + 4 * j) = cp[j];
+            if (cx + 4 * j < A.w[0])
+                *reinterpret_cast<uint32_t *>(A.dst[0] + (size_t)(cy - A.row0[0]) * (size_t)A.dst0_pitch + cx + 4 * j) = cp[j];
     }
     __syncthreads();
 
@@ -240,8 +245,8 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
                 packed |= (uint32_t)v << (8 * q);
             }
             // the tile's own part (not the halo) goes to HBM
-            if (ry >= Hn && y < A.h[k + 1] && xb >= Xn && xb < A.w[k + 1]) {
-                uint8_t *row = A.dst[k + 1] + (size_t)y * (size_t)A.pitch[k + 1];
+            if (ry >= Hn && y >= A.row0[k + 1] && y < A.row1[k + 1] && xb >= Xn && xb < A.w[k + 1]) {
+                uint8_t *row = A.dst[k + 1] + (size_t)(y - A.row0[k + 1]) * (size_t)A.pitch[k + 1];
                 if (xb + 3 < Xn + Tn && xb + 3 < A.w[k + 1]) {
                     *reinterpret_cast<uint32_t *>(row + xb) = packed;
                 } else {

@@ -45,12 +45,13 @@ class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
-                 shard=None, iters: int = 1):
+                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
         p.width, p.height, p.levels, p.window, p.mode, p.device = width, height, levels, window, MODES[mode], device
         p.iters = iters
+        p.local_corner, p.patch_size = int(bool(local_corner)), int(patch_size)
         self.shard = shard
         if shard is not None:
             p.sharded = 1
@@ -140,6 +141,12 @@ class Session:
         return p.value
 
     # ---- stream pipeline: one launch per frame, flow of pair p ready after frame p+3
+    def corner_status(self, stream=None) -> int:
+        """local_corner sessions: OR of the "shift left the patch at level k" bits since the last call (0 = all exact)."""
+        st = C.c_int(0)
+        check(self.L.ofx_session_corner_status(self._h, C.byref(st), _stream_ptr(stream)), "corner_status")
+        return int(st.value)
+
     def stream_begin(self):
         check(self.L.ofx_session_stream_begin(self._h), "stream_begin")
 

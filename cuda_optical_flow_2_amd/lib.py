@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("own_y0", C.c_int * OFX_MAX_LEVELS), ("own_y1", C.c_int * OFX_MAX_LEVELS),
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
                 ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
-                ("iters", C.c_int), ("reserved", C.c_int * 7)]
+                ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("reserved", C.c_int * 5)]
 
 
 _vp = C.c_void_p
@@ -87,6 +87,7 @@ _SIGS = {
     "ofx_session_run_level": [_vp, _i, _vp],
     "ofx_session_swap": [_vp],
     "ofx_session_stream_begin": [_vp],
+    "ofx_session_corner_status": [_vp, C.POINTER(_i), _vp],
     "ofx_session_stream_submit": [_vp, _vp, _i, _vp, C.POINTER(_i)],
     "ofx_session_stream_drain": [_vp, _vp, C.POINTER(_i)],
     "ofx_stream_launch": [_vp, _i, _i, _vp],

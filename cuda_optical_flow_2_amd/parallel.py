@@ -13,7 +13,14 @@ wider halo of the NEW FRAME's level 0 once (the frame arrives in every rank's HB
 the coarser levels itself -- a few per cent more downsampling work instead of a latency-bound exchange per level.  The
 one true dependency between ranks is the reference's shift vector, which is formed from PIXEL 0 of every coarser flow
 level (OptFlowCPU.cpp:255-266): rank 0 owns that corner, runs the corner kernel, and broadcasts the 2*levels floats --
-one small collective per frame pair.
+one small collective per frame pair ("broadcast" corner mode).
+
+"local" corner mode removes that collective too.  Pixel 0's flow only depends on the top-left (radius + 2 + shift)
+pixels of every level, and the pyramid's stencil (2x-1 .. 2x+1) never reaches past column/row 2*w_k - 1, so the pyramid
+of a frame's top-left PATCH equals the top-left part of the frame's pyramid at every level.  Every rank is handed the
+whole frame anyway, so each rank builds that small patch pyramid next to its row block and runs the corner chain
+itself: ranks share nothing, and each of them can run the one-launch-per-frame stream pipeline
+(ofx_session_stream_*).  The shift is exact while it stays inside the patch (the session reports when it does not).
 """
 from __future__ import annotations
 
@@ -80,11 +87,12 @@ class ShardPlan:
 class HipBackend:
     """The device-resident session of libofx_hip.so behind the operations ShardedFlow needs."""
 
-    def __init__(self, plan: ShardPlan, mode: str, device: int):
+    def __init__(self, plan: ShardPlan, mode: str, device: int, local_corner: bool = False, patch_size: int = 0):
         from . import engine
 
         self.plan = plan
-        self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan)
+        self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan,
+                                      local_corner=local_corner, patch_size=patch_size)
         self._views = {}
         # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
         self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
@@ -145,11 +153,25 @@ class HipBackend:
 class ShardedFlow:
     """One frame pair per step(), row-sharded over the ranks of the default process group."""
 
-    def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True):
+    def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True,
+                 corner="broadcast", patch_size=0):
+        assert corner in ("broadcast", "local")
         self.plan = ShardPlan(width, height, levels, window, rank, world, margin)
-        self.rank, self.world, self.pipelined = rank, world, pipelined
-        self.backend = backend if backend is not None else HipBackend(self.plan, mode, device)
+        self.rank, self.world, self.pipelined, self.corner = rank, world, pipelined, corner
+        self.backend = backend if backend is not None else HipBackend(self.plan, mode, device, corner == "local", patch_size)
         self.session = getattr(self.backend, "session", None)
+
+    # ---- stream pipeline (corner == "local", HIP sessions): one launch per frame on every rank, nothing between ranks
+    def stream_begin(self):
+        assert self.corner == "local", "the sharded stream pipeline needs the corner flows computed locally"
+        self.session.stream_begin()
+
+    def stream_submit(self, frame) -> int:
+        """Next frame of the stream; returns the pair whose flow (this rank's rows) the launch writes, or -1."""
+        return self.session.stream_submit(frame)
+
+    def stream_drain(self) -> int:
+        return self.session.stream_drain()
 
     def push_frame(self, frame):
         """Make `frame` the previous frame (priming, main.cu:203-209)."""
@@ -163,6 +185,14 @@ class ShardedFlow:
         import torch.distributed as dist
 
         b = self.backend
+        if self.corner == "local":
+            # pair-at-a-time form of the local mode (the CPU stand-in of the tests; HIP sessions use stream_submit)
+            b.load_frame(frame)
+            b.build_pyramid()
+            b.corner_flows_local()
+            b.run_levels()
+            b.swap()
+            return
         if self.pipelined and not check_margin and hasattr(b, "pipelined_step"):
             b.pipelined_step(frame, self.rank, self.world)
             return

@@ -116,10 +116,26 @@ typedef struct ofx_stream_stages {
     int frame_pitch, w, h, pyr_levels;
     uint8_t *d_levels[OFX_MAX_LEVELS];
     int pitches[OFX_MAX_LEVELS];
-    /* corner flows: descriptors as for ofx_corner_flows (corner_levels = 0: none) */
+    /* row windows of the pyramid's destination planes (row-sharded callers): with pyr_windowed != 0, d_levels[k] holds the
+     * global rows [pyr_row0[k], pyr_row0[k] + pyr_rows[k]) of level k and only those are written; d_frame is always the
+     * whole frame. */
+    int pyr_windowed;
+    int pyr_row0[OFX_MAX_LEVELS], pyr_rows[OFX_MAX_LEVELS];
+    /* a second, small pyramid of the same frame's top-left patch_w x patch_h corner (patch_levels = 0: none).  A
+     * pyramid of such a patch equals the top-left part of the frame's pyramid at every level (the stencil 2x-1..2x+1
+     * never reaches past column/row 2*w_k-1), which lets a rank that does not hold row 0 compute the corner flows. */
+    int patch_w, patch_h, patch_levels;
+    uint8_t *d_patch_levels[OFX_MAX_LEVELS];
+    int patch_pitches[OFX_MAX_LEVELS];
+    /* corner flows: descriptors as for ofx_corner_flows (corner_levels = 0: none).  corner_cols[k] > 0: the planes of
+     * level k are a patch holding columns [0, corner_cols[k]) and rows [0, geom.rows) of the geom.w x geom.h level;
+     * d_corner_status (may be NULL): bit k is OR-ed in when level k needed a pixel inside the image but outside its planes
+     * (the shift left the patch: the result for that pair is not the reference's). */
     ofx_lk_desc corner[OFX_MAX_LEVELS];
     int corner_levels;
     float *d_uv;
+    int corner_cols[OFX_MAX_LEVELS];
+    int *d_corner_status;
     /* shifts and fused LK */
     ofx_shift_desc shift[OFX_MAX_LEVELS];
     int n_shift;
@@ -257,10 +273,22 @@ typedef struct ofx_params {
     int comp_y0[OFX_MAX_LEVELS], comp_y1[OFX_MAX_LEVELS];
     /* refinement iterations per level (extension, lk_float only): 0 or 1 = the reference (no refinement) */
     int iters;
-    int reserved[7];
+    /* Sharded sessions: compute the corner flows (the reference's shift vectors, formed from pixel 0 of every coarser
+     * flow level) LOCALLY from a small top-left patch of every frame instead of receiving them from the rank that owns
+     * row 0.  Every frame handed to the session is the whole frame, so the patch is always at hand; with it a rank
+     * needs nothing from any other rank and can run the one-launch-per-frame stream pipeline
+     * (ofx_session_stream_*).  patch_size: level-0 side of the square patch, 0 = automatic
+     * (2^(levels-1) * (window/2 + 2 + 8), at least 256, clipped to the frame).  The shift is exact while it stays inside
+     * the patch; ofx_session_corner_status reports when it did not. */
+    int local_corner;
+    int patch_size;
+    int reserved[5];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
+/* local_corner sessions: *h_status receives (and the session clears) the OR over all pairs so far of "level k's shift
+ * left the patch" bits; 0 = every corner flow was computed from pixels the patch holds.  Synchronises `stream`. */
+int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream);
 int ofx_session_destroy(ofx_session *s);
 /* Load the NEXT frame's level 0 (1ch, tightly packed w bytes per row, full frame) from host / device memory. */
 int ofx_session_set_frame_host(ofx_session *s, const uint8_t *h_gray1, void *stream);

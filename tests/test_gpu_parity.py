@@ -336,6 +336,105 @@ def test_stream_pipeline_equals_plain_sequence(eng, cfg):
     s.close()
 
 
+@pytest.mark.parametrize("cfg", [(640, 480, 4, 9, "lk_float", 4), (640, 480, 4, 9, "compat_cpu", 3), (1920, 1088, 5, 7, "lk_float", 8),
+                                 (768, 512, 3, 15, "lk_float", 2)])
+def test_sharded_stream_sessions_with_local_corner(eng, cfg):
+    """Row-sharded sessions running the ONE-LAUNCH stream pipeline with the corner flows computed locally from each
+    frame's top-left patch (ofx_params.local_corner): R logical ranks on one device, nothing passed between them, must
+    reproduce the unsharded plain sequence bit for bit for every pair, and no rank may report that the shift left its
+    patch."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, mode, R = cfg
+    nf = 6
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.4 * i, 0.8 * i, seed=17)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, mode)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+
+    plans = [ShardPlan(w, h, L, win, r, R) for r in range(R)]
+    ranks = [eng.Session(w, h, L, win, mode, shard=pl, local_corner=True) for pl in plans]
+    got = {}
+    for s in ranks:
+        s.stream_begin()
+    def snap(done):
+        if done >= 1:
+            got[done] = [[s.flow(k)[0].clone() for k in range(L)] for s in ranks]
+    for i in range(nf):
+        dones = [s.stream_submit(frames[i]) for s in ranks]
+        assert len(set(dones)) == 1
+        snap(dones[0])
+    while True:
+        dones = [s.stream_drain() for s in ranks]
+        assert len(set(dones)) == 1
+        if dones[0] == -2:
+            break
+        snap(dones[0])
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(1, nf))
+    for p in range(1, nf):
+        for k in range(L):
+            full = torch.cat([got[p][r][k] for r in range(R)], dim=0).cpu().numpy()
+            assert_same(full, want[p][k], f"{mode} pair {p} level {k}")
+    for s in ranks:
+        assert s.corner_status() == 0
+        s.close()
+
+
+def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
+    """ofx_session_corner_status must say exactly when a corner shift needed pixels the patch does not hold.  Pixel 0's
+    flow is normally tiny (the zero border dominates its gradients), so the frames are a dark-cornered ramp whose
+    brightness steps by d between frames: that yields corner shifts of several pixels, against a deliberately minimal
+    patch.  The expected bits are recomputed here from the shift vectors the session publishes."""
+    import torch
+
+    w, h, L, win, patch = 640, 480, 3, 3, 12
+    R = win // 2
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    base = xx / 2 + yy / 3 + xx * yy / 64
+    seen_miss = False
+    for d in (10, 20, 40, 80):
+        a = np.clip(np.floor(base), 0, 255).astype(np.uint8)
+        b = np.clip(np.floor(base + d), 0, 255).astype(np.uint8)
+        s = eng.Session(w, h, L, win, "lk_float", local_corner=True, patch_size=patch)
+        s.stream_begin()
+        expected = 0
+        for i, f in enumerate([a, b, a, b]):
+            s.stream_submit(torch.from_numpy(f).cuda())
+            torch.cuda.synchronize()
+            if i >= 2:   # the corner stage of tick i handled pair i-1, whose vectors sit in slot (i-1) & 1
+                uvp = s.uv(0).data_ptr()
+                both = eng.DeviceView(uvp, (2 * 12 * 2,), "<f4").tensor().cpu().numpy().reshape(2, 12, 2)
+                # uv(0) points at the session's current slot, which the stream pipeline does not advance: slot 0 is first
+                uv = both[(i - 1) & 1]
+                for k in range(L - 1):
+                    wk, hk, pk = w >> k, h >> k, patch >> k
+                    u, v = np.float32(uv[k][0]), np.float32(uv[k][1])
+                    for y in range(-1, R + 2):
+                        for x in range(-1, R + 2):
+                            if not (0 <= x < wk and 0 <= y < hk):
+                                continue
+                            tx, ty = np.float32(x) + u, np.float32(y) + v
+                            if tx > -1 and tx < wk and ty > -1 and ty < hk and (int(tx) >= pk or int(ty) >= pk):
+                                expected |= 1 << k
+        while s.stream_drain() != -2:
+            pass
+        torch.cuda.synchronize()
+        got = s.corner_status()
+        assert got == expected, (d, got, expected)
+        assert s.corner_status() == 0   # reading clears it
+        seen_miss = seen_miss or got != 0
+        s.close()
+    assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
+
+
 def test_sharded_driver_single_rank_pipelined(eng):
     """parallel.ShardedFlow with world = 1 drives the staged halves (stage_frame / corner_flows / stage_shift /
     solve_staged on the session's aux stream) exactly as bench.py --gpus N does on every rank; the broadcast is the only

@@ -53,11 +53,17 @@ def test_plan_rejects_impossible_splits():
 class OracleBackend:
     """numpy/oracle stand-in for HipBackend: one rank's buffers hold only the rows plan.buf says they hold."""
 
-    def __init__(self, plan, mode):
+    def __init__(self, plan, mode, patch_size=0):
         import torch
         from oracle import Oracle
 
         self.plan, self.mode, self.orc = plan, mode, Oracle()
+        # "local" corner mode: the top-left patch of every frame as a pyramid of its own (side as in ofx_session_create)
+        step = 1 << (plan.levels - 1)
+        side = patch_size if patch_size > 0 else max(256, step * (plan.window // 2 + 2 + 8))
+        side = -(-side // step) * step
+        self.patch_wh = (min(side, plan.width), min(side, plan.height))
+        self.patch_prev, self.patch_next = None, None
         L = plan.levels
         self.w = [plan.width >> k for k in range(L)]
         self.h = [plan.height >> k for k in range(L)]
@@ -68,6 +74,42 @@ class OracleBackend:
     def load_frame(self, frame):
         b0, b1 = self.plan.buf[0]
         self.next[0] = np.asarray(frame)[b0:b1].copy()
+        pw, ph = self.patch_wh
+        pyr = [np.asarray(frame)[:ph, :pw].copy()]
+        for k in range(1, self.plan.levels):   # the patch is downsampled like an image of its own
+            pyr.append(self.orc.downscale_gaussian(synth.to_3ch(pyr[-1]))[:, :, 0].copy())
+        self.patch_next = pyr
+
+    def corner_flows_local(self):
+        """The corner chain from this rank's own patch pyramids: no rank owns anything the others need."""
+        L, r = self.plan.levels, self.plan.window // 2
+        f0 = {}
+        for k in range(L - 1, -1, -1):
+            u = v = np.float32(0)
+            for j in range(L - 1, k, -1):
+                m = np.float32(1 << (j - k))
+                u = np.float32(u + m * f0[j][0])
+                v = np.float32(v + m * f0[j][1])
+            w, h = self.w[k], self.h[k]
+            rows, cols = min(h, r + 2), min(w, r + 2)
+            prev, nxt_src = self.patch_prev[k], self.patch_next[k]
+            assert prev.shape[0] >= rows and prev.shape[1] >= cols
+            if k != L - 1:
+                self.uv_all[2 * k], self.uv_all[2 * k + 1] = float(u), float(v)
+                nxt = np.zeros((rows, cols), np.uint8)
+                for y in range(rows):
+                    for x in range(cols):
+                        tx, ty = np.float32(x) + u, np.float32(y) + v
+                        if tx > -1 and tx < w and ty > -1 and ty < h:   # OptFlowCPU.cpp:270-276
+                            nx, ny = int(np.trunc(tx)), int(np.trunc(ty))
+                            assert ny < nxt_src.shape[0] and nx < nxt_src.shape[1], "shift target outside the patch"
+                            nxt[y, x] = nxt_src[ny, nx]
+                        else:
+                            nxt[y, x] = nxt_src[y, x] if 3 * (y * w + x) < w * h else 0
+            else:
+                nxt = nxt_src[:rows, :cols]
+            # pixel 0's window reaches column/row r and its derivatives r + 1: the (r+2)^2 crop is all it sees
+            f0[k] = self._level(prev[:rows, :cols], nxt)[0, 0]
 
     def build_pyramid(self):
         p = self.plan
@@ -147,6 +189,7 @@ class OracleBackend:
 
     def swap(self):
         self.prev, self.next = self.next, [None] * self.plan.levels
+        self.patch_prev, self.patch_next = self.patch_next, None
 
     def flow(self, level):
         import torch
@@ -160,7 +203,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, cfg, mode):
+def _rank_main(rank, world, port, cfg, mode, corner="broadcast"):
     import torch.distributed as dist
     from conftest import assert_same
     from oracle import Oracle
@@ -172,11 +215,12 @@ def _rank_main(rank, world, port, cfg, mode):
         w, h, L, win, margin = cfg
         frames = [synth.smooth_pair(w, h, 1.5 * i, 0.75 * i, seed=5)[1] for i in range(3)]
         plan = ShardPlan(w, h, L, win, rank, world, margin)
-        sf = ShardedFlow(w, h, L, win, mode, rank, world, margin=margin, backend=OracleBackend(plan, mode))
+        sf = ShardedFlow(w, h, L, win, mode, rank, world, margin=margin, backend=OracleBackend(plan, mode, patch_size=48),
+                         corner=corner)
         sf.push_frame(frames[0])
         orc = Oracle()
         for i in (1, 2):
-            sf.step(frames[i], check_margin=True)
+            sf.step(frames[i], check_margin=corner == "broadcast")
             want, _, _ = orc.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), L, win, mode, exact_sums=True)
             for k in range(L):
                 got = sf.gather_flow(k).numpy()
@@ -192,3 +236,13 @@ def test_sharded_flow_gloo(world, mode):
 
     cfg = (96, 144, 3, 5, 8)  # 36 coarse rows; window 5; halo margin 8
     mp.spawn(_rank_main, args=(world, _free_port(), cfg, mode), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_sharded_flow_gloo_local_corner(mode):
+    """corner="local": every rank forms the shift vectors from its own 48x48 top-left patch pyramid; no broadcast.  The
+    collective left in the test is gather_flow's all_gather, which only reassembles the result for the comparison."""
+    import torch.multiprocessing as mp
+
+    cfg = (96, 144, 3, 5, 8)
+    mp.spawn(_rank_main, args=(2, _free_port(), cfg, mode, "local"), nprocs=2, join=True)

@@ -1,0 +1,33 @@
+"""What one rank of an N-rank row-sharded run costs, measured on ONE GPU: a sharded local-corner session for rank r of N
+running the stream pipeline alone (ranks share nothing on the data path, so this is the per-rank time of the real run).
+    python tools/shard_sim.py [workload] [N ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cuda_optical_flow_2_amd import engine, synth
+from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+WORK = {"4k": (3840, 2160, 5, 9), "1080p": (1920, 1080, 4, 7), "8k": (7680, 4320, 6, 15)}
+name = sys.argv[1] if len(sys.argv) > 1 else "4k"
+worlds = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
+w, h, L, win = WORK[name]
+frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1]).cuda() for i in range(4)]
+st = torch.cuda.Stream()
+torch.cuda.set_stream(st)
+for N in worlds:
+    res = []
+    for r in sorted({0, N // 2, N - 1}):
+        s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True)
+        s.stream_begin()
+        for i in range(20):
+            s.stream_submit(frames[i % 4])
+        torch.cuda.synchronize()
+        steps = 300
+        t0 = time.perf_counter()
+        for i in range(steps):
+            s.stream_submit(frames[i % 4])
+        torch.cuda.synchronize()
+        res.append((r, (time.perf_counter() - t0) / steps * 1e6))
+        s.close()
+    worst = max(t for _, t in res)
+    print(f"{name} N={N}: " + "  ".join(f"rank {r}: {t:.1f} us" for r, t in res) + f"  -> {w * h / worst:.0f} Mpix/s if all ranks run like the slowest")
