@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=2, choices=[1, 2],
+                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
@@ -115,20 +117,23 @@ def main():
     w, h, levels, window = WORKLOADS[args.workload]
     # a short ring of resident frames: a smooth texture translating by (2,1) px per frame
     nframes = 4
-    frames = [synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1] for i in range(nframes)]
+    # experiments: OFX_BENCH_MOTION="mx,my" scales the per-frame translation (2,1) px; "0,0" = identical frames
+    mx, my = (float(t) for t in os.environ.get("OFX_BENCH_MOTION", "1,1").split(","))
+    frames = [synth.smooth_pair(w, h, 2.0 * i * mx, 1.0 * i * my)[1] for i in range(nframes)]
     d_frames = [torch.from_numpy(f).cuda() for f in frames]
 
     if world == 1 and not force_dist:
         if args.iters > 1:
             args.path = "plain"
-        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters)
+        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
+                              stream_batch=args.batch if args.path == "stream" else 1)
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
             # one launch per frame: pyramid(frame j) | corner(pair j-1) | fused LK(pair j-2, global shift in its loads) side by side in
             # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
             sess.stream_begin()
-            for i in range(3):
+            for i in range(6):
                 sess.stream_submit(d_frames[i % nframes])
 
             def step(i):
@@ -152,11 +157,12 @@ def main():
         # One pair row-sharded over the ranks (strong scaling).  Default: every rank runs the one-launch-per-frame stream
         # pipeline on its row block with the corner flows computed from its own top-left patch -- no collective on the data
         # path; --shard-corner broadcast keeps rank 0's corner kernel + one RCCL broadcast per pair (staged halves).
-        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner)
+        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner,
+                                      stream_batch=args.batch)
         sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
-            for i in range(3):
+            for i in range(6):
                 driver.stream_submit(d_frames[i % nframes])
 
             def step(i):
@@ -212,6 +218,9 @@ def main():
             # (a rank of a sharded run builds the rows it owns)
             lk_bytes += 5 * sum((w >> k) * ((h >> k) if driver is None else (driver.plan.own[k][1] - driver.plan.own[k][0]))
                                 for k in range(1, levels))
+        stream_like = (driver is None and args.path == "stream") or sharded_stream
+        pairs_per_launch = args.batch if stream_like else 1   # a stream tick carries args.batch frames / pairs
+        lk_bytes *= pairs_per_launch
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -246,13 +255,14 @@ def main():
                      "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)")),
             },
             "roofline": {
-                "bound": "hbm", "kernel": ("stream_kernel (one launch per pair: fused LK of all levels for pair j-2 | corner flows of pair j-1 | pyramid of "
-                            "frame j; bytes = 10 B/px LK + 5 B/px pyramid)"
+                "bound": "hbm", "kernel": (f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
+                            f"{pairs_per_launch} pair(s) before | fused LK of all levels of the {pairs_per_launch} pair(s) before those; bytes per pair = "
+                            "10 B/px LK + 5 B/px pyramid)"
                            if (driver is None and args.path == "stream") or sharded_stream else
                            "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": lk_bytes, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),
+                "algorithmic_bytes_per_launch": lk_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),
                 "launches_timed": k_n, "timed_in": "second pass over the same steps with hipEventRecord around each launch on its stream",
                 "traffic": traffic,
             },

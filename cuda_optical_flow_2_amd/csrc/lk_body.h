@@ -33,6 +33,9 @@ struct LkTable {
 // knows they came from the kernarg segment and would fall back to flat_* instructions with 64-bit VALU address
 // arithmetic; these casts put them back into the global address space (scalar base + 32-bit lane offset).
 #define OFX_GLOBAL __attribute__((address_space(1)))
+#ifndef OFX_LK_NT_STORES
+#define OFX_LK_NT_STORES 1
+#endif
 struct __attribute__((packed)) UnalignedU32 {
     uint32_t v;
 };
@@ -56,7 +59,16 @@ __device__ __forceinline__ uint32_t gload_u32_unaligned(const uint8_t *base, uin
 }
 typedef OFX_GLOBAL float *gfloat_ptr;
 __device__ __forceinline__ gfloat_ptr gptr_f32(float *base, uint32_t idx) { return (gfloat_ptr)base + lane_off(idx); }
-__device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b) { *(OFX_GLOBAL f32x2 *)p = f32x2{a, b}; }
+// the flow is written once and never read back by this launch: streaming stores keep it from displacing the image rows
+// the trailing window re-reads from L2
+__device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b)
+{
+#if OFX_LK_NT_STORES
+    __builtin_nontemporal_store(f32x2{a, b}, (OFX_GLOBAL f32x2 *)p);
+#else
+    *(OFX_GLOBAL f32x2 *)p = f32x2{a, b};
+#endif
+}
 __device__ __forceinline__ void gstore_i32(int32_t *p, int32_t v) { *(OFX_GLOBAL int32_t *)p = v; }
 
 // a wave-uniform value, made opaque in an SGPR (no instruction is emitted)

@@ -40,23 +40,23 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 }
 
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
-// Launch j of a frame stream runs, as disjoint block ranges of ONE grid,
-//     pyramid(frame j)  |  corner flows(pair j-1)  |  fused LK(pair j-2)
-// (a stand-alone shift stage can be scheduled as a fourth range; the session does not use it since the shift moved into
-// the LK loads).  Each stage consumes what launch j-1 wrote, so there is no synchronisation inside the launch and none between streams;
-// the small latency-bound stages run in the shadow of the VALU-bound LK stage.  Blocks are 256 threads; an LK block is
-// four independent LK waves.
+// A tick of a frame stream runs, as disjoint block ranges of ONE grid,
+//     pyramid(newest frame(s))  |  corner flows(earlier pair(s))  |  fused LK(still earlier pair(s))
+// Each stage consumes what earlier launches wrote, so there is no synchronisation inside the launch and none between
+// streams; the small latency-bound stages run in the shadow of the VALU-bound LK stage.  Blocks are 256 threads; an LK
+// block is four independent LK waves; the corner block runs one wave per pair.
+constexpr int kPyrStages = 2 * OFX_STREAM_MAX_BATCH; // per frame of the tick: its pyramid and its top-left patch pyramid
 struct StreamArgs {
     LkTable lk;
-    ShiftTable sh;
-    PyrArgs pyr;
-    CornerArgs corner;
-    PyrArgs patch; // pyramid of the frame's top-left patch (sharded sessions: local corner flows)
-    // block 0 = corner wave; [1, pyr_first) LK (four waves per block); [pyr_first, patch_first) pyramid;
-    // [patch_first, sh_first) patch pyramid; [sh_first, end) shift.
-    // The LK blocks come first and are planned for 3 waves per SIMD (lk_wave_target): they all start at once and run for the
-    // whole launch, while the short staging blocks stream through the remaining slots underneath them.
-    int pyr_first, pyr_blocks_x, patch_first, patch_blocks_x, sh_first;
+    PyrArgs pyr[kPyrStages];
+    CornerArgs corner[OFX_STREAM_MAX_BATCH];
+    // blocks [0, OFX_STREAM_MAX_BATCH) = one corner wave each; [.., first[0]) LK (four waves per block);
+    // [first[i], first[i+1]) pyramid stage i.
+    // The LK blocks come first and are planned for a whole number of waves per SIMD (lk_wave_target): they all start at
+    // once and run for the whole launch, while the short staging blocks stream through the remaining slots underneath.
+    int first[kPyrStages + 1];
+    int blocks_x[kPyrStages];
+    int n_corner;
 };
 
 // lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu would spill there
@@ -68,21 +68,19 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
-    if (b == 0) {
-        if (S.corner.levels > 0 && tid < 64) corner_wave<MODE>(S.corner, tid, reinterpret_cast<float *>(lds));
-    } else if (b < S.pyr_first) {
-        // readfirstlane: the wave index is uniform, and everything derived from it (strip rows, row pointers, loop
-        // counters) must live in SGPRs as it does in the stand-alone kernel
-        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-        lk_wave<R, MODE, false>(S.lk, 4 * (b - 1) + wv, tid & 63);
-    } else if (b < S.patch_first) {
-        const int pb = b - S.pyr_first;
-        pyramid_block(S.pyr, pb % S.pyr_blocks_x, pb / S.pyr_blocks_x + S.pyr.by0, tid, lds);
-    } else if (b < S.sh_first) {
-        const int pb = b - S.patch_first;
-        pyramid_block(S.patch, pb % S.patch_blocks_x, pb / S.patch_blocks_x, tid, lds);
+    // readfirstlane: the wave index is uniform, and everything derived from it (strip rows, row pointers, loop counters)
+    // must live in SGPRs as it does in the stand-alone kernel
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (b < OFX_STREAM_MAX_BATCH) {
+        // one corner chain per block (wave 0), so that the chains land on different CUs
+        if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds));
+    } else if (b < S.first[0]) {
+        lk_wave<R, MODE, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
     } else {
-        shift_block(S.sh, b - S.sh_first, tid);
+        int i = 0;
+        while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
+        const int pb = b - S.first[i];
+        pyramid_block(S.pyr[i], pb % S.blocks_x[i], pb / S.blocks_x[i] + S.pyr[i].by0, tid, lds);
     }
 }
 
@@ -136,7 +134,7 @@ int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
 // is not a whole number per SIMD makes the fuller SIMDs set the time.  `reserve` slots per SIMD are left to the other
 // stages of the stream kernel.
 template <typename K>
-int lk_wave_target(K kernel, int threads, size_t lds, int reserve)
+int lk_wave_target(K kernel, int threads, size_t lds, int reserve, int dflt_per_simd)
 {
     int dev = 0, cus = 256, per_cu = 0;
     hipDeviceProp_t prop;
@@ -144,7 +142,7 @@ int lk_wave_target(K kernel, int threads, size_t lds, int reserve)
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu <= 0) per_cu = 8 * 64 / threads;
     (void)hipGetLastError();
     const int occ = per_cu * (threads / 64) / 4; // waves per SIMD (4 SIMDs per CU)
-    int per_simd = env_int("OFX_LK_WAVES_PER_SIMD", 3);
+    int per_simd = env_int("OFX_LK_WAVES_PER_SIMD", dflt_per_simd);
     if (per_simd > occ - reserve) per_simd = occ - reserve;
     if (per_simd < 1) per_simd = 1;
     return env_int("OFX_LK_TARGET_WAVES", cus * 4 * per_simd);
@@ -153,7 +151,7 @@ int lk_wave_target(K kernel, int threads, size_t lds, int reserve)
 template <int R, int MODE, bool SUMS>
 int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS>, 64, 0, 0);
+    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS>, 64, 0, 0, 3);
     LkTable t{};
     const int blocks = plan_table<R>(lv, n, capacity, &t);
     hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3((unsigned)blocks), dim3(64), 0, st, t);
@@ -162,40 +160,46 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 }
 
 template <int R, int MODE>
-int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, int pyr_blocks, int patch_blocks, int sh_blocks, size_t lds, hipStream_t st)
+int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1);
+    // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
+    // carries two (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
+    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 2);
+    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 4);
+    int pairs = 0;
+    for (int i = 0; i < n; ++i) pairs += (lv[i].a.w == lv[0].a.w && lv[i].a.h == lv[0].a.h) ? 1 : 0;
+    const int capacity = pairs >= 2 ? capacity2 : capacity1;
     int lk_blocks = 0;
     if (n > 0) lk_blocks = ofx_div_up(plan_table<R>(lv, n, capacity, &S.lk), 4);
-    S.pyr_first = 1 + lk_blocks;
-    S.patch_first = S.pyr_first + pyr_blocks;
-    S.sh_first = S.patch_first + patch_blocks;
-    const int blocks = S.sh_first + sh_blocks;
-    if (lds < 2 * OFX_MAX_LEVELS * sizeof(float)) lds = 2 * OFX_MAX_LEVELS * sizeof(float); // the corner wave's scratch
+    S.first[0] = OFX_STREAM_MAX_BATCH + lk_blocks;
+    for (int i = 0; i < kPyrStages; ++i) S.first[i + 1] = S.first[i] + stage_blocks[i];
+    const int blocks = S.first[kPyrStages];
+    const size_t corner_lds = (size_t)2 * OFX_MAX_LEVELS * sizeof(float); // a corner wave's scratch
+    if (lds < corner_lds) lds = corner_lds;
     hipLaunchKernelGGL((stream_kernel<R, MODE>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
 template <int MODE>
-int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, int pb, int qb, int sb, size_t lds, hipStream_t st)
+int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_stream_r<1, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 2: return launch_stream_r<2, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 3: return launch_stream_r<3, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 4: return launch_stream_r<4, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 5: return launch_stream_r<5, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 6: return launch_stream_r<6, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 7: return launch_stream_r<7, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 8: return launch_stream_r<8, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 9: return launch_stream_r<9, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 10: return launch_stream_r<10, MODE>(lv, n, S, pb, qb, sb, lds, st);
-    case 11: return launch_stream_r<11, MODE>(lv, n, S, pb, qb, sb, lds, st);
+    case 1: return launch_stream_r<1, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 2: return launch_stream_r<2, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 3: return launch_stream_r<3, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 4: return launch_stream_r<4, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 5: return launch_stream_r<5, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 6: return launch_stream_r<6, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 7: return launch_stream_r<7, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 8: return launch_stream_r<8, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 9: return launch_stream_r<9, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 10: return launch_stream_r<10, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 11: return launch_stream_r<11, MODE>(lv, n, S, stage_blocks, lds, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, pb, qb, sb, lds, st);
+        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, stage_blocks, lds, st);
     }
     ofx_set_error("ofx_stream_launch: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
@@ -289,42 +293,47 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     OFX_REQUIRE(g != nullptr, "ofx_stream_launch: null argument");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_stream_launch: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_stream_launch: bad mode %d", mode);
+    OFX_REQUIRE(g->n_pyr >= 0 && g->n_pyr <= OFX_STREAM_MAX_BATCH && g->n_corner >= 0 && g->n_corner <= OFX_STREAM_MAX_BATCH,
+                "ofx_stream_launch: at most %d frames / pairs per tick", OFX_STREAM_MAX_BATCH);
     StreamArgs S{};
     size_t lds = 0;
-    int pyr_blocks = 0, patch_blocks = 0, sh_blocks = 0;
-    if (g->pyr_levels >= 2) {
+    int stage_blocks[kPyrStages] = {0};
+    int any = 0;
+    for (int i = 0; i < kPyrStages; ++i) S.blocks_x[i] = 1;
+    for (int i = 0; i < g->n_pyr; ++i) {
+        const ofx_pyramid_stage &P = g->pyr[i];
+        if (P.levels < 2) continue;
         int bx = 0, by = 0;
-        OFX_TRY(ofx_pyramid_args(g->d_frame, g->frame_pitch, g->w, g->h, g->d_levels, g->pitches, g->pyr_levels, g->d_levels[0],
-                                 g->pitches[0], g->pyr_windowed ? g->pyr_row0 : nullptr, g->pyr_windowed ? g->pyr_rows : nullptr, &S.pyr,
-                                 &lds, &bx, &by));
-        S.pyr_blocks_x = bx;
-        pyr_blocks = bx * by;
-    } else {
-        S.pyr_blocks_x = 1;
+        size_t need = 0;
+        OFX_TRY(ofx_pyramid_args(P.d_frame, P.frame_pitch, P.w, P.h, P.d_levels, P.pitches, P.levels, P.d_levels[0], P.pitches[0],
+                                 P.windowed ? P.row0 : nullptr, P.windowed ? P.rows : nullptr, &S.pyr[2 * i], &need, &bx, &by));
+        S.blocks_x[2 * i] = bx;
+        stage_blocks[2 * i] = bx * by;
+        lds = need > lds ? need : lds;
+        if (P.patch_levels >= 2) {
+            OFX_REQUIRE(P.patch_w > 0 && P.patch_h > 0 && P.patch_w <= P.w && P.patch_h <= P.h,
+                        "ofx_stream_launch: the patch must lie inside the frame");
+            OFX_TRY(ofx_pyramid_args(P.d_frame, P.frame_pitch, P.patch_w, P.patch_h, P.d_patch_levels, P.patch_pitches, P.patch_levels,
+                                     P.d_patch_levels[0], P.patch_pitches[0], nullptr, nullptr, &S.pyr[2 * i + 1], &need, &bx, &by));
+            S.blocks_x[2 * i + 1] = bx;
+            stage_blocks[2 * i + 1] = bx * by;
+            lds = need > lds ? need : lds;
+        }
+        any += stage_blocks[2 * i] + stage_blocks[2 * i + 1];
     }
-    S.patch_blocks_x = 1;
-    if (g->patch_levels >= 2) {
-        OFX_REQUIRE(g->pyr_levels >= 2 && g->patch_w > 0 && g->patch_h > 0 && g->patch_w <= g->w && g->patch_h <= g->h,
-                    "ofx_stream_launch: the patch pyramid needs a frame and a patch inside it");
-        int bx = 0, by = 0;
-        size_t lds2 = 0;
-        OFX_TRY(ofx_pyramid_args(g->d_frame, g->frame_pitch, g->patch_w, g->patch_h, g->d_patch_levels, g->patch_pitches, g->patch_levels,
-                                 g->d_patch_levels[0], g->patch_pitches[0], nullptr, nullptr, &S.patch, &lds2, &bx, &by));
-        S.patch_blocks_x = bx;
-        patch_blocks = bx * by;
-        lds = lds2 > lds ? lds2 : lds;
+    for (int i = 0; i < g->n_corner; ++i) {
+        const ofx_corner_stage &C = g->corner[i];
+        OFX_REQUIRE(C.levels > 0, "ofx_stream_launch: empty corner stage");
+        OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &S.corner[i]));
     }
-    if (g->corner_levels > 0)
-        OFX_TRY(ofx_corner_args(g->corner, g->corner_levels, window, mode, g->d_uv, g->corner_cols, g->d_corner_status, &S.corner));
-    if (g->n_shift > 0) OFX_TRY(ofx_shift_table(g->shift, g->n_shift, &S.sh, &sh_blocks));
+    S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LEVELS];
     int m = 0;
     if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
-    if (pyr_blocks == 0 && patch_blocks == 0 && sh_blocks == 0 && m == 0 && g->corner_levels <= 0) return OFX_OK;
+    if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
-    return mode == OFX_MODE_LK_FLOAT
-               ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, pyr_blocks, patch_blocks, sh_blocks, lds, st)
-               : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, pyr_blocks, patch_blocks, sh_blocks, lds, st);
+    return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, stage_blocks, lds, st)
+                                     : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, stage_blocks, lds, st);
 }
 
 extern "C" int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream)

@@ -13,6 +13,8 @@
 
 namespace {
 constexpr size_t kAlign = 256;
+constexpr int kSets = 8;    // image sets: 3 rotate in the pair-at-a-time paths; the stream pipeline uses 5 (one frame per tick) or 8 (two)
+constexpr int kUvSlots = 4; // shift-vector slots: 2 alternate per pair, the two-frame stream tick needs 4
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 } // namespace
 
@@ -24,7 +26,7 @@ struct ofx_session {
     int cmp0[OFX_MAX_LEVELS]{}, cmp1[OFX_MAX_LEVELS]{}; // rows this rank downsamples itself
     // storage: three image sets rotate through the roles prev -> (free) -> next, two shifted-scratch sets alternate, so
     // that the pipelined path can build frame i+1's pyramid / corner / shift while pair i's LK launch is running
-    uint8_t *img[5][OFX_MAX_LEVELS]{};                  // sets 0..2 rotate in the pair-at-a-time paths, all 5 in the stream pipeline
+    uint8_t *img[kSets][OFX_MAX_LEVELS]{};              // see kSets
     uint8_t *sh[2][OFX_MAX_LEVELS]{};
     int cur = 0, sht = 0;                               // img[cur] = previous frame, img[(cur+1)%3] = next frame
     uint8_t *plane[3][OFX_MAX_LEVELS]{};                // role view: 0 prev, 1 next, 2 shifted scratch
@@ -38,14 +40,16 @@ struct ofx_session {
     float *uv_cur() { return uv + (size_t)uv_slot * 2 * OFX_MAX_LEVELS; }
     long stream_n = -1;      // ticks of the stream pipeline so far (-1: not streaming)
     long stream_frames = -1; // total frames, known once draining starts (-1: still receiving)
-    // index of the newest frame whose pyramid exists once tick f has been issued
-    long stream_last_frame(long f, bool has_frame) const { return stream_frames >= 0 ? stream_frames - 1 : (has_frame ? f : f - 1); }
     int pitch0_next() const { return pitch[0]; }
     // local_corner: the top-left patch of every frame as a pyramid of its own (same 5 sets as img)
-    uint8_t *pimg[5][OFX_MAX_LEVELS]{};
+    uint8_t *pimg[kSets][OFX_MAX_LEVELS]{};
     int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
     int *corner_status = nullptr;
-    float *flow[OFX_MAX_LEVELS]{};
+    float *flow[OFX_MAX_LEVELS]{};       // where results are read from: flowset[0], or the newest pair's set in a two-frame stream
+    float *flowset[2][OFX_MAX_LEVELS]{}; // pair p's flow goes to set p & 1 when stream_batch == 2 (one set otherwise)
+    const uint8_t *held_frame = nullptr; // two-frame stream tick: the even frame waiting for its partner
+    int held_pitch = 0;
+    long reported = 0;                   // highest pair reported complete by the stream pipeline
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
     void *arena = nullptr;
@@ -87,6 +91,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(p->window >= 3 && (p->window & 1), "ofx_session_create: window must be odd and >= 3");
     OFX_REQUIRE(p->mode == OFX_MODE_COMPAT_CPU || p->mode == OFX_MODE_LK_FLOAT, "ofx_session_create: bad mode %d", p->mode);
     OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
+    OFX_REQUIRE(p->stream_batch >= 0 && p->stream_batch <= OFX_STREAM_MAX_BATCH, "ofx_session_create: stream_batch %d out of range",
+                p->stream_batch);
+    OFX_REQUIRE(p->stream_batch < 2 || 2 * p->levels <= OFX_MAX_LEVELS, "ofx_session_create: stream_batch 2 needs levels <= %d",
+                OFX_MAX_LEVELS / 2);
     OFX_REQUIRE(p->iters <= 1 || (p->mode == OFX_MODE_LK_FLOAT && !p->sharded),
                 "ofx_session_create: refinement iterations need mode lk_float and an unsharded session");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
@@ -102,7 +110,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(s != nullptr, "ofx_session_create: out of host memory");
     s->p = *p;
     size_t total = 0;
-    std::vector<size_t> off_plane[7], off_flow;
+    std::vector<size_t> off_plane[kSets + 2], off_flow, off_flow2;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
         s->h[k] = p->height >> k;
@@ -130,15 +138,18 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
-        for (int t = 0; t < 7; ++t) { // 5 image sets + 2 shifted sets
+        for (int t = 0; t < kSets + 2; ++t) { // image sets + 2 shifted sets
             off_plane[t].push_back(total);
             total += plane_bytes;
         }
         off_flow.push_back(total);
         const size_t own_rows = (size_t)(s->own1[k] - s->own0[k]);
-        total += align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
+        const size_t flow_bytes = align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
+        total += flow_bytes;
+        off_flow2.push_back(total); // second flow set: a two-frame stream tick writes the flows of two pairs
+        if (p->stream_batch >= 2) total += flow_bytes;
     }
-    std::vector<size_t> off_patch[5];
+    std::vector<size_t> off_patch[kSets];
     if (p->local_corner) {
         const int step = 1 << (p->levels - 1);
         int side = p->patch_size > 0 ? p->patch_size : step * ((p->window >> 1) + 2 + 8);
@@ -150,7 +161,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->ph[k] = ph0 >> k;
             s->ppitch[k] = (int)align_up((size_t)s->pw[k], 64);
             const size_t bytes = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
-            for (int t = 0; t < 5; ++t) {
+            for (int t = 0; t < kSets; ++t) {
                 off_patch[t].push_back(total);
                 total += bytes;
             }
@@ -167,7 +178,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     const size_t off_status = total;
     total += kAlign;
     const size_t off_uv = total;
-    total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * 2, kAlign); // two sets (the stream pipeline alternates)
+    total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * kUvSlots, kAlign);
     const size_t off_staging = total;
     total += align_up((size_t)p->width * (size_t)p->height * 3, kAlign);
 
@@ -187,13 +198,15 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     }
     uint8_t *base = static_cast<uint8_t *>(s->arena);
     for (int k = 0; k < p->levels; ++k) {
-        for (int t = 0; t < 5; ++t) s->img[t][k] = base + off_plane[t][k];
-        for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[5 + t][k];
-        s->flow[k] = reinterpret_cast<float *>(base + off_flow[k]);
+        for (int t = 0; t < kSets; ++t) s->img[t][k] = base + off_plane[t][k];
+        for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[kSets + t][k];
+        s->flowset[0][k] = reinterpret_cast<float *>(base + off_flow[k]);
+        s->flowset[1][k] = reinterpret_cast<float *>(base + (p->stream_batch >= 2 ? off_flow2[k] : off_flow[k]));
+        s->flow[k] = s->flowset[0][k];
     }
     if (p->local_corner)
         for (int k = 0; k < p->levels; ++k)
-            for (int t = 0; t < 5; ++t) s->pimg[t][k] = base + off_patch[t][k];
+            for (int t = 0; t < kSets; ++t) s->pimg[t][k] = base + off_patch[t][k];
     s->corner_status = reinterpret_cast<int *>(base + off_status);
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = base + off_staging;
@@ -613,11 +626,98 @@ extern "C" int ofx_session_corner_status(ofx_session *s, int *h_status, void *st
     return OFX_OK;
 }
 
-// ---- stream pipeline: one launch per frame ---------------------------------------------------------------------------
-// Frame f (0-based) submitted at tick f; tick f runs  pyramid(frame f) | corner(pair f-1) | LK(pair f-2, shift fused)
-// where pair p is (frame p-1 -> frame p).  Frame f lives in image set f mod 5 and pair p's shift vectors in slot p mod 2,
-// which makes every stage of a tick independent of the others; ticks are ordered by the stream.  The flow of pair p is
-// complete after tick p+2.
+// ---- stream pipeline: one launch per tick of B frames ----------------------------------------------------------------
+// Frame f (0-based) belongs to tick f / B (B = stream_batch, 1 or 2).  Pair p is (frame p-1 -> frame p).  The tick whose
+// first frame is f0 runs, side by side in one grid,
+//     pyramid(frames f0 .. f0+B-1) | corner(pairs f0-B .. f0-1) | LK(pairs f0-2B .. f0-B-1, shift fused)
+// so every stage consumes what earlier ticks wrote and the ticks are ordered by the stream.  Frame f lives in image set
+// f mod S and pair p's shift vectors in slot p mod U (B = 1: S = 5, U = 2; B = 2: S = 8, U = 4): a set is last read by
+// LK(pair f+1), one or two ticks before it is rewritten; a slot is read by LK(pair p) a tick before pair p+U's corner
+// stage rewrites it.  With B = 2 the flows of pair p go to flow set p & 1.  After a tick every pair <= f0-B-1 is done.
+static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *pitches, int n_frames, void *stream, int *completed_pair)
+{
+    const int B = s->p.stream_batch >= 2 ? 2 : 1;
+    const int sets = B == 2 ? 8 : 5, slots = B == 2 ? 4 : 2;
+    const long f0 = s->stream_n; // index of the first frame of this tick
+    const int L = s->p.levels;
+    auto uvslot = [&](long pair) { return s->uv + (size_t)(pair % slots) * 2 * OFX_MAX_LEVELS; };
+    auto set_of = [&](long frame) { return (int)(frame % sets); };
+    const long last_frame = s->stream_frames >= 0 ? s->stream_frames - 1 : f0 + n_frames - 1;
+    ofx_stream_stages g;
+    memset(&g, 0, sizeof g);
+    for (int i = 0; i < n_frames; ++i) { // pyramid(frame f0 + i)
+        OFX_REQUIRE(pitches[i] >= s->w[0] && (pitches[i] & 3) == 0 && ((uintptr_t)frames[i] & 3) == 0,
+                    "ofx_session_stream_submit: frame must be 4-byte aligned with a pitch multiple of 4 and >= width");
+        ofx_pyramid_stage &P = g.pyr[g.n_pyr++];
+        const int set = set_of(f0 + i);
+        P.d_frame = frames[i];
+        P.frame_pitch = pitches[i];
+        P.w = s->w[0];
+        P.h = s->h[0];
+        P.levels = L;
+        P.windowed = s->p.sharded ? 1 : 0;
+        for (int k = 0; k < L; ++k) {
+            P.d_levels[k] = s->img[set][k];
+            P.pitches[k] = s->pitch[k];
+            P.row0[k] = s->buf0[k];
+            P.rows[k] = s->buf1[k] - s->buf0[k];
+        }
+        if (s->p.local_corner) { // the same frame's top-left patch, as a pyramid of its own
+            P.patch_w = s->pw[0];
+            P.patch_h = s->ph[0];
+            P.patch_levels = L;
+            for (int k = 0; k < L; ++k) {
+                P.d_patch_levels[k] = s->pimg[set][k];
+                P.patch_pitches[k] = s->ppitch[k];
+            }
+        }
+    }
+    for (long pc = f0 - B; pc <= f0 - 1; ++pc) { // corner(pair pc): both pyramids complete since the previous tick
+        if (pc < 1 || pc > last_frame) continue;
+        ofx_corner_stage &C = g.corner[g.n_corner++];
+        C.levels = L;
+        C.d_uv = uvslot(pc);
+        for (int k = 0; k < L; ++k) {
+            if (s->p.local_corner) {
+                ofx_geom pg{s->w[k], s->h[k], s->ppitch[k], 0, s->ph[k], 0, s->ph[k]};
+                C.level[k] = ofx_lk_desc{s->pimg[set_of(pc - 1)][k], s->pimg[set_of(pc)][k], pg, nullptr, 0, nullptr, 0};
+                C.cols[k] = s->pw[k];
+            } else {
+                C.level[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr, 0};
+            }
+        }
+        if (s->p.local_corner) C.d_status = s->corner_status;
+    }
+    long newest = -1;
+    for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
+        if (pl < 1 || pl > last_frame) continue;
+        float *const *fl = s->flowset[B == 2 ? (pl & 1) : 0];
+        for (int k = L - 1; k >= 0; --k)
+            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, s->own0[k], s->own1[k]),
+                                         fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0};
+        newest = pl;
+    }
+    *completed_pair = -1;
+    if (newest > s->reported) {
+        *completed_pair = (int)newest;
+        s->reported = newest;
+        for (int k = 0; k < L; ++k) s->flow[k] = s->flowset[B == 2 ? (newest & 1) : 0][k];
+    }
+    static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }(); // timing experiments only
+    if (skip & 1) g.n_pyr = 0;
+    if (skip & 2) g.n_corner = 0;
+    if (skip & 8) g.n_lk = 0;
+    const bool timed = s->timing && (g.n_lk > 0 || (skip & 8)) && s->ev_used + 2 <= s->ev.size();
+    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
+    OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
+    if (timed) {
+        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
+        s->ev_used += 2;
+    }
+    s->stream_n = f0 + B;
+    return OFX_OK;
+}
+
 extern "C" int ofx_session_stream_begin(ofx_session *s)
 {
     OFX_REQUIRE(s, "ofx_session_stream_begin: null session");
@@ -627,84 +727,16 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
     OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
     s->stream_n = 0;
+    s->stream_frames = -1;
+    s->held_frame = nullptr;
+    s->reported = 0;
     s->have_prev = s->have_next = s->staged = false;
+    for (int k = 0; k < s->p.levels; ++k) s->flow[k] = s->flowset[0][k];
     return OFX_OK;
 }
 
-static int stream_tick(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair)
-{
-    const long f = s->stream_n; // index of the frame arriving with this tick (if any)
-    const int L = s->p.levels, halo = (s->p.window >> 1) + 1;
-    float *uvset[2] = {s->uv, s->uv + 2 * OFX_MAX_LEVELS};
-    auto set_of = [&](long frame) { return (int)(frame % 5); };
-    ofx_stream_stages g;
-    memset(&g, 0, sizeof g);
-    if (d_gray1) { // pyramid(frame f)
-        OFX_REQUIRE(pitch >= s->w[0] && (pitch & 3) == 0 && ((uintptr_t)d_gray1 & 3) == 0,
-                    "ofx_session_stream_submit: frame must be 4-byte aligned with a pitch multiple of 4 and >= width");
-        g.d_frame = d_gray1;
-        g.frame_pitch = pitch;
-        g.w = s->w[0];
-        g.h = s->h[0];
-        g.pyr_levels = L;
-        g.pyr_windowed = s->p.sharded ? 1 : 0;
-        for (int k = 0; k < L; ++k) {
-            g.d_levels[k] = s->img[set_of(f)][k];
-            g.pitches[k] = s->pitch[k];
-            g.pyr_row0[k] = s->buf0[k];
-            g.pyr_rows[k] = s->buf1[k] - s->buf0[k];
-        }
-        if (s->p.local_corner) { // the same frame's top-left patch, as a pyramid of its own
-            g.patch_w = s->pw[0];
-            g.patch_h = s->ph[0];
-            g.patch_levels = L;
-            for (int k = 0; k < L; ++k) {
-                g.d_patch_levels[k] = s->pimg[set_of(f)][k];
-                g.patch_pitches[k] = s->ppitch[k];
-            }
-        }
-    }
-    const long pc = f - 1; // corner(pair pc): frames pc-1 -> pc, both pyramids complete since the previous tick
-    if (pc >= 1 && pc <= s->stream_last_frame(f, d_gray1 != nullptr)) {
-        g.corner_levels = L;
-        g.d_uv = uvset[pc & 1];
-        for (int k = 0; k < L; ++k) {
-            if (s->p.local_corner) {
-                ofx_geom pg{s->w[k], s->h[k], s->ppitch[k], 0, s->ph[k], 0, s->ph[k]};
-                g.corner[k] = ofx_lk_desc{s->pimg[set_of(pc - 1)][k], s->pimg[set_of(pc)][k], pg, nullptr, 0, nullptr, 0};
-                g.corner_cols[k] = s->pw[k];
-            } else {
-                g.corner[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr, 0};
-            }
-        }
-        if (s->p.local_corner) g.d_corner_status = s->corner_status;
-    }
-    const long pl = f - 2; // LK(pair pl), reading next through the shift vectors the previous tick's corner stage wrote
-    *completed_pair = -1;
-    if (pl >= 1 && pl <= s->stream_last_frame(f, d_gray1 != nullptr)) {
-        for (int k = L - 1; k >= 0; --k)
-            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, s->own0[k], s->own1[k]),
-                                         s->flow[k], s->own0[k], k == L - 1 ? nullptr : uvset[pl & 1] + 2 * k, 0};
-        *completed_pair = (int)pl;
-    }
-    (void)halo;
-    static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }(); // timing experiments only
-    if (skip & 1) g.pyr_levels = 0;
-    if (skip & 2) g.corner_levels = 0;
-    if (skip & 8) g.n_lk = 0;
-    const bool timed = s->timing && (g.n_lk > 0 || (skip & 8)) && s->ev_used + 2 <= s->ev.size();
-    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
-    OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
-    if (timed) {
-        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
-        s->ev_used += 2;
-    }
-    s->stream_n = f + 1;
-    return OFX_OK;
-}
-
-// Submit the next frame of the stream (one launch).  *completed_pair (may be NULL) receives the index p of the pair
-// (frame p-1 -> frame p, frames counted from 0) whose flow this launch writes, or -1 while the pipeline fills.
+// Submit the next frame of the stream.  *completed_pair (may be NULL) receives the highest pair (frame p-1 -> frame p,
+// frames counted from 0) whose flow is complete after this call in `stream` order, or -1 when the call completed none.
 extern "C" int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair)
 {
     OFX_REQUIRE(s && d_gray1, "ofx_session_stream_submit: null argument");
@@ -714,11 +746,29 @@ extern "C" int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1,
     }
     OFX_REQUIRE(s->stream_frames < 0, "ofx_session_stream_submit: the stream is being drained");
     int dummy = -1;
-    return stream_tick(s, d_gray1, pitch, stream, completed_pair ? completed_pair : &dummy);
+    if (!completed_pair) completed_pair = &dummy;
+    if (s->p.stream_batch >= 2 && s->held_frame == nullptr) { // first frame of a two-frame tick: wait for its partner
+        s->held_frame = d_gray1;
+        s->held_pitch = pitch;
+        *completed_pair = -1;
+        return OFX_OK;
+    }
+    const uint8_t *fr[2] = {d_gray1, nullptr};
+    int pt[2] = {pitch, 0};
+    int n = 1;
+    if (s->held_frame) {
+        fr[0] = s->held_frame;
+        pt[0] = s->held_pitch;
+        fr[1] = d_gray1;
+        pt[1] = pitch;
+        n = 2;
+        s->held_frame = nullptr;
+    }
+    return stream_tick(s, fr, pt, n, stream, completed_pair);
 }
 
-// Run one more tick without a new frame; call until it reports -2 in *completed_pair (pipeline empty).  Two ticks
-// drain a full pipeline.
+// Run one more tick without a new frame (a frame still waiting for its partner goes out with it); call until it
+// reports -2 in *completed_pair (pipeline empty).  Two ticks drain a full pipeline.
 extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair)
 {
     OFX_REQUIRE(s && completed_pair, "ofx_session_stream_drain: null argument");
@@ -726,14 +776,32 @@ extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *compl
         ofx_set_error("ofx_session_stream_drain: not streaming");
         return OFX_E_STATE;
     }
-    if (s->stream_frames < 0) s->stream_frames = s->stream_n; // number of frames the stream received
-    if (s->stream_n >= s->stream_frames + 2) {
+    const int B = s->p.stream_batch >= 2 ? 2 : 1;
+    const uint8_t *fr[2] = {s->held_frame, nullptr};
+    int pt[2] = {s->held_pitch, 0};
+    const int n = s->held_frame ? 1 : 0;
+    s->held_frame = nullptr;
+    if (s->stream_frames < 0) s->stream_frames = s->stream_n + n; // number of frames the stream received
+    (void)B;
+    if (n == 0 && s->reported >= s->stream_frames - 1) { // every pair (the last one is stream_frames - 1) has been reported
         *completed_pair = -2;
         s->stream_n = -1;
         s->stream_frames = -1;
         return OFX_OK;
     }
-    return stream_tick(s, nullptr, 0, stream, completed_pair);
+    return stream_tick(s, fr, pt, n, stream, completed_pair);
+}
+
+extern "C" int ofx_session_flow_of(ofx_session *s, int pair, int level, float **d_ptr, int *row0, int *rows)
+{
+    OFX_REQUIRE(s && level >= 0 && level < s->p.levels, "ofx_session_flow_of: bad arguments");
+    const int B = s->p.stream_batch >= 2 ? 2 : 1;
+    OFX_REQUIRE(pair >= 1 && pair <= s->reported && pair > s->reported - B,
+                "ofx_session_flow_of: pair %d is not among the newest %d completed pairs (newest: %ld)", pair, B, s->reported);
+    if (d_ptr) *d_ptr = s->flowset[B == 2 ? (pair & 1) : 0][level];
+    if (row0) *row0 = s->own0[level];
+    if (rows) *rows = s->own1[level] - s->own0[level];
+    return OFX_OK;
 }
 
 // gpu::calc_opt_flow (OptFlowGpu.cuh:33, OptFlowGpu.cu:1909-1979) with host pointers: upload both images and the

@@ -45,13 +45,14 @@ class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
-                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0):
+                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
         p.width, p.height, p.levels, p.window, p.mode, p.device = width, height, levels, window, MODES[mode], device
         p.iters = iters
         p.local_corner, p.patch_size = int(bool(local_corner)), int(patch_size)
+        p.stream_batch = int(stream_batch)
         self.shard = shard
         if shard is not None:
             p.sharded = 1
@@ -188,6 +189,13 @@ class Session:
         """torch float32 view [own_rows, w, 2] of the level's flow, and the global index of its first row."""
         ptr, r0, rows = _vp(), C.c_int(), C.c_int()
         check(self.L.ofx_session_flow(self._h, level, C.byref(ptr), C.byref(r0), C.byref(rows)), "session_flow")
+        w = self.width >> level
+        return DeviceView(ptr.value, (rows.value, w, 2), "<f4").tensor(), r0.value
+
+    def flow_of(self, pair: int, level: int):
+        """As flow(), for one of the newest completed pairs of the stream pipeline (two of them with stream_batch = 2)."""
+        ptr, r0, rows = _vp(), C.c_int(), C.c_int()
+        check(self.L.ofx_session_flow_of(self._h, pair, level, C.byref(ptr), C.byref(r0), C.byref(rows)), "session_flow_of")
         w = self.width >> level
         return DeviceView(ptr.value, (rows.value, w, 2), "<f4").tensor(), r0.value
 

@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("own_y0", C.c_int * OFX_MAX_LEVELS), ("own_y1", C.c_int * OFX_MAX_LEVELS),
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
                 ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
-                ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("reserved", C.c_int * 5)]
+                ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("stream_batch", C.c_int), ("reserved", C.c_int * 4)]
 
 
 _vp = C.c_void_p
@@ -88,6 +88,7 @@ _SIGS = {
     "ofx_session_swap": [_vp],
     "ofx_session_stream_begin": [_vp],
     "ofx_session_corner_status": [_vp, C.POINTER(_i), _vp],
+    "ofx_session_flow_of": [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "ofx_session_stream_submit": [_vp, _vp, _i, _vp, C.POINTER(_i)],
     "ofx_session_stream_drain": [_vp, _vp, C.POINTER(_i)],
     "ofx_stream_launch": [_vp, _i, _i, _vp],

@@ -106,40 +106,47 @@ typedef struct ofx_shift_desc {
     const float *d_uv;
 } ofx_shift_desc;
 
-/* One tick of the frame-stream pipeline in ONE launch: pyramid of the newest frame | corner flows of the pair before |
- * shifts of the pair before that | fused LK of the pair before that, as disjoint block ranges of one grid.  Every stage
- * only reads what earlier launches wrote, so the stages need no synchronisation; a stage is skipped when its count is 0.
+/* One tick of the frame-stream pipeline in ONE launch: the pyramids of the newest frame(s) | the corner flows of earlier
+ * pair(s) | the fused LK of still earlier pair(s), as disjoint block ranges of one grid.  Every stage only reads what
+ * earlier launches wrote, so the stages need no synchronisation; a stage is skipped when its count is 0.  A tick may
+ * carry up to OFX_STREAM_MAX_BATCH frames / pairs per stage (ofx_params.stream_batch): the LK items of two pairs then
+ * share one launch, which doubles the strip height (half the priming rows per output row) and halves the launches.
  * ofx_session_stream_submit drives this; it is exposed for callers that manage their own buffers. */
-typedef struct ofx_stream_stages {
-    /* pyramid: levels 1..pyr_levels-1 from d_frame, plus a copy of level 0 into d_levels[0] (pyr_levels = 0: none) */
+#define OFX_STREAM_MAX_BATCH 2
+typedef struct ofx_pyramid_stage {
+    /* levels 1..levels-1 from d_frame, plus a copy of level 0 into d_levels[0] */
     const uint8_t *d_frame;
-    int frame_pitch, w, h, pyr_levels;
+    int frame_pitch, w, h, levels;
     uint8_t *d_levels[OFX_MAX_LEVELS];
     int pitches[OFX_MAX_LEVELS];
-    /* row windows of the pyramid's destination planes (row-sharded callers): with pyr_windowed != 0, d_levels[k] holds the
-     * global rows [pyr_row0[k], pyr_row0[k] + pyr_rows[k]) of level k and only those are written; d_frame is always the
-     * whole frame. */
-    int pyr_windowed;
-    int pyr_row0[OFX_MAX_LEVELS], pyr_rows[OFX_MAX_LEVELS];
+    /* row windows of the destination planes (row-sharded callers): with windowed != 0, d_levels[k] holds the global rows
+     * [row0[k], row0[k] + rows[k]) of level k and only those are written; d_frame is always the whole frame. */
+    int windowed;
+    int row0[OFX_MAX_LEVELS], rows[OFX_MAX_LEVELS];
     /* a second, small pyramid of the same frame's top-left patch_w x patch_h corner (patch_levels = 0: none).  A
      * pyramid of such a patch equals the top-left part of the frame's pyramid at every level (the stencil 2x-1..2x+1
      * never reaches past column/row 2*w_k-1), which lets a rank that does not hold row 0 compute the corner flows. */
     int patch_w, patch_h, patch_levels;
     uint8_t *d_patch_levels[OFX_MAX_LEVELS];
     int patch_pitches[OFX_MAX_LEVELS];
-    /* corner flows: descriptors as for ofx_corner_flows (corner_levels = 0: none).  corner_cols[k] > 0: the planes of
-     * level k are a patch holding columns [0, corner_cols[k]) and rows [0, geom.rows) of the geom.w x geom.h level;
-     * d_corner_status (may be NULL): bit k is OR-ed in when level k needed a pixel inside the image but outside its planes
-     * (the shift left the patch: the result for that pair is not the reference's). */
-    ofx_lk_desc corner[OFX_MAX_LEVELS];
-    int corner_levels;
+} ofx_pyramid_stage;
+typedef struct ofx_corner_stage {
+    /* descriptors as for ofx_corner_flows.  cols[k] > 0: the planes of level k are a patch holding columns [0, cols[k])
+     * and rows [0, geom.rows) of the geom.w x geom.h level; d_status (may be NULL): bit k is OR-ed in when level k needed
+     * a pixel inside the image but outside its planes (the shift left the patch: that pair's result is not the
+     * reference's). */
+    ofx_lk_desc level[OFX_MAX_LEVELS];
+    int levels;
     float *d_uv;
-    int corner_cols[OFX_MAX_LEVELS];
-    int *d_corner_status;
-    /* shifts and fused LK */
-    ofx_shift_desc shift[OFX_MAX_LEVELS];
-    int n_shift;
-    ofx_lk_desc lk[OFX_MAX_LEVELS];
+    int cols[OFX_MAX_LEVELS];
+    int *d_status;
+} ofx_corner_stage;
+typedef struct ofx_stream_stages {
+    ofx_pyramid_stage pyr[OFX_STREAM_MAX_BATCH];
+    int n_pyr;
+    ofx_corner_stage corner[OFX_STREAM_MAX_BATCH];
+    int n_corner;
+    ofx_lk_desc lk[OFX_MAX_LEVELS]; /* the LK items of every pair of the tick (levels x pairs <= OFX_MAX_LEVELS) */
     int n_lk;
 } ofx_stream_stages;
 int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
@@ -282,7 +289,10 @@ typedef struct ofx_params {
      * the patch; ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
-    int reserved[5];
+    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 = one launch per two frames (see
+     * ofx_session_stream_submit). */
+    int stream_batch;
+    int reserved[4];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
@@ -321,15 +331,22 @@ int ofx_session_stage_frame(ofx_session *s, const uint8_t *d_gray1, int pitch, v
 int ofx_session_stage_shift(ofx_session *s, void *aux_stream);
 int ofx_session_solve_staged(ofx_session *s, void *stream);
 int ofx_session_aux_stream(ofx_session *s, void **stream);
-/* Stream pipeline (highest throughput, single GPU): every submitted frame costs ONE launch (ofx_stream_launch) in which
- * the pyramid of that frame, the corner flows of the pair before and the fused LK (shift included) of the pair before
- * that run side by side.  The flow of pair p (frame p-1 -> frame p, frames counted from 0) is written by the launch of
- * frame p+2; *completed_pair reports which pair a call produced (-1 while the pipeline fills).  After the
- * last frame call ofx_session_stream_drain until it reports -2.  Results are bit-identical to the pair-at-a-time paths.
- * The frame buffer must stay valid until the launch that received it has finished. */
+/* Stream pipeline (highest throughput): ONE launch (ofx_stream_launch) per tick of B = ofx_params.stream_batch frames
+ * (1 or 2), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
+ * included) of the B pairs before that run side by side.  With B = 1 every call launches and the flow of pair p (frame
+ * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  With B = 2 a call with an even frame
+ * index only remembers the frame (its buffer must stay unmodified until the next call has returned) and the next call
+ * launches for both; pairs complete two at a time, one tick later.  *completed_pair receives the HIGHEST pair complete
+ * after the call in `stream` order (all lower ones are complete too; -1 while the pipeline fills); the flows of the
+ * newest B pairs are at ofx_session_flow_of.  After the last frame call ofx_session_stream_drain until it reports -2.
+ * Results are bit-identical to the pair-at-a-time paths.  A frame buffer must stay valid until the launch that
+ * received it has finished. */
 int ofx_session_stream_begin(ofx_session *s);
 int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair);
 int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair);
+/* Flow of `pair` at `level` while it is one of the newest stream_batch completed pairs of the stream pipeline (pairs
+ * alternate between two flow sets when stream_batch == 2).  Same outputs as ofx_session_flow. */
+int ofx_session_flow_of(ofx_session *s, int pair, int level, float **d_ptr, int *row0, int *rows);
 /* prev <- next (main.cu:270-272). */
 int ofx_session_swap(ofx_session *s);
 /* Device pointers / geometry of the session's buffers. which: 0 = prev, 1 = next, 2 = shifted scratch. */

@@ -435,6 +435,66 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 
+@pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
+                                 (640, 480, 6, 9, "lk_float", 1, 8)])
+def test_two_frame_stream_ticks_equal_plain_sequence(eng, cfg):
+    """ofx_params.stream_batch = 2: one launch per TWO frames (the LK items of two pairs share a launch: taller strips,
+    half the launches).  Calls with an even frame index only remember the frame; pairs complete two at a time and are
+    read through ofx_session_flow_of.  Every pair must carry the bits of the plain sequence -- also for row-sharded
+    sessions with local corner flows (third config: 4 logical ranks) and for odd frame counts (the last frame goes out
+    alone when the stream is drained)."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, mode, R, nf = cfg
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.2 * i, -0.6 * i, seed=41)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, mode)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+
+    if R == 1:
+        ranks = [eng.Session(w, h, L, win, mode, stream_batch=2)]
+    else:
+        ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=2) for r in range(R)]
+    got = {}
+    for s in ranks:
+        s.stream_begin()
+    seen = 0
+    def snap(done):
+        nonlocal seen
+        if done >= 1:
+            for p in range(max(seen + 1, done - 1), done + 1):   # the newest two pairs are readable
+                got[p] = [[s.flow_of(p, k)[0].clone() for k in range(L)] for s in ranks]
+            assert done - seen <= 2
+            seen = done
+    for i in range(nf):
+        dones = [s.stream_submit(frames[i]) for s in ranks]
+        assert len(set(dones)) == 1
+        if i % 2 == 0:
+            assert dones[0] == -1   # the frame is only remembered
+        snap(dones[0])
+    while True:
+        dones = [s.stream_drain() for s in ranks]
+        assert len(set(dones)) == 1
+        if dones[0] == -2:
+            break
+        snap(dones[0])
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(1, nf))
+    for p in range(1, nf):
+        for k in range(L):
+            full = torch.cat([got[p][r][k] for r in range(len(ranks))], dim=0).cpu().numpy()
+            assert_same(full, want[p][k], f"{mode} pair {p} level {k}")
+    for s in ranks:
+        s.close()
+
+
 def test_sharded_driver_single_rank_pipelined(eng):
     """parallel.ShardedFlow with world = 1 drives the staged halves (stage_frame / corner_flows / stage_shift /
     solve_staged on the session's aux stream) exactly as bench.py --gpus N does on every rank; the broadcast is the only
