@@ -481,7 +481,9 @@ __device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&i
 }
 
 // One wave of the fused level kernel: `wave` indexes the (level, tile, strip) work items of the table, `lane` is 0..63.
-template <int R, int MODE, bool SUMS>
+// MAY_ACC: the launch may contain accumulating items (refinement iterations); false compiles that path out (the stream
+// kernel never has any, and the extra live registers would push it over its 96-VGPR budget)
+template <int R, int MODE, bool SUMS, bool MAY_ACC = true>
 __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 {
     using G = TileGeom<R>;
@@ -660,6 +662,22 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         // returns within a type, so a wait for a load that has younger stores outstanding is a wait for those stores too.
         const uint32_t pf_ip = fetch_row(A.prev, yy + 2), pf_op = fetch_out_prev(yo + 2);
         const NextRaw pf_in = fetch_next(yy + 2), pf_on = fetch_out_next(yo + 2);
+        // a refinement launch adds to the flow already there: its 8 floats are fetched with the rows and waited for once
+        const bool emit = s >= 2 * R;
+        const int y = yy - R;
+        const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
+        const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
+        float old_uv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (!SUMS && MAY_ACC) {
+            if (A.accumulate && emit && out_lane) {
+                float *frow = A.flow + 2 * rowpix;
+                pin_scalar(frow);
+                const gfloat_ptr src = gptr_f32(frow, 2u * (uint32_t)cb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (cb + j < A.w) old_uv[2 * j] = src[2 * j], old_uv[2 * j + 1] = src[2 * j + 1];
+            }
+        }
 
         // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
         // window only counts once its row has entered (yo >= y_first)
@@ -728,10 +746,18 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 #endif
         // ---- emit output row y = yy - R ------------------------------------------------------------------------
         // (one call site for take_rows, after the arithmetic and before the stores)
+#if !OFX_LK_PACKED
         const bool emit = s >= 2 * R;
         const int y = yy - R;
         const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
         const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
+        float old_uv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if constexpr (!SUMS && MAY_ACC) {
+            if (A.accumulate && emit && out_lane)
+                for (int j = 0; j < 4; ++j)
+                    if (cb + j < A.w) old_uv[2 * j] = A.flow[2 * (rowpix + cb + j)], old_uv[2 * j + 1] = A.flow[2 * (rowpix + cb + j) + 1];
+        }
+#endif
         int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
         float uv[8];
         if (emit) {
@@ -764,13 +790,11 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
                 float *frow = A.flow + 2 * rowpix;
                 pin_scalar(frow);
                 const gfloat_ptr dst = gptr_f32(frow, 2u * (uint32_t)cb);
-                if (A.accumulate) {
+                if constexpr (MAY_ACC) {
+                    if (A.accumulate) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (cb + j < A.w) {
-                            uv[2 * j] = dst[2 * j] + uv[2 * j];
-                            uv[2 * j + 1] = dst[2 * j + 1] + uv[2 * j + 1];
-                        }
+                        for (int j = 0; j < 8; ++j) uv[j] = old_uv[j] + uv[j];
+                    }
                 }
                 if (cb + 3 < A.w) {
                     // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)

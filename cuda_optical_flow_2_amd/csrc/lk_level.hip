@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // one corner chain per block (wave 0), so that the chains land on different CUs
         if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds));
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
+        lk_wave<R, MODE, false, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
