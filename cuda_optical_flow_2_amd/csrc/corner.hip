@@ -17,7 +17,8 @@ template <int MODE>
 __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
 {
     __shared__ float f0[2 * OFX_MAX_LEVELS];
-    corner_wave<MODE>(A, (int)threadIdx.x, f0);
+    __shared__ __attribute__((aligned(16))) uint8_t cache[kCornerTileBytes + OFX_MAX_LEVELS * kCornerCacheBytes];
+    corner_wave<MODE>(A, (int)threadIdx.x, f0, cache);
 }
 
 } // namespace
@@ -27,6 +28,7 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
 {
     OFX_REQUIRE(levels && d_uv && n_levels >= 1 && n_levels <= OFX_MAX_LEVELS, "ofx_corner_flows: bad arguments");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_corner_flows: window must be odd and >= 3 (got %d)", window);
+    OFX_REQUIRE((window >> 1) <= kCornerMaxRadius, "ofx_corner_flows: window %d not supported (at most %d)", window, 2 * kCornerMaxRadius + 1);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_corner_flows: bad mode %d", mode);
     CornerArgs a{};
     a.levels = n_levels;

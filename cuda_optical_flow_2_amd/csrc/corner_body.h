@@ -21,23 +21,38 @@ struct CornerArgs {
     int levels, radius;
 };
 
-// Pixel fetches are branch-free: the address is clamped into the buffer and the value masked afterwards, so all the
-// loads of a tap are issued back to back and cost one memory round trip (conditional loads made hipcc wait per load).
-__device__ __forceinline__ int pix(const uint8_t *img, const CornerLevel &L, int x, int y, int &miss)
+// The chain's pixels come from LDS: before the walk, the wave copies the top-left corner of every level -- 16 x 16 bytes of
+// prev (the window and its 3x3 stencils reach column/row radius + 1 <= 13) and 32 x 32 bytes of next (the same plus
+// >= 18 pixels of shift) -- with all its loads in flight at once, i.e. ONE memory round trip instead of one per level
+// (the chain was 13 us of mostly memory latency; a rank of an 8-way sharded 4K pair spends less than that on LK).  A
+// shifted target outside the cached corner falls back to a global load.
+constexpr int kCornerPrevDim = 16, kCornerNextDim = 32;
+constexpr int kCornerCacheBytes = kCornerPrevDim * kCornerPrevDim + kCornerNextDim * kCornerNextDim; // per level
+constexpr int kCornerTileBytes = 2 * kCornerPrevDim * kCornerPrevDim;                                 // the resolved tiles
+constexpr int kCornerMaxRadius = kCornerPrevDim - 3; // the cached prev corner must hold the window and its stencils
+
+struct CornerCache {
+    const uint8_t *prev; // [16][16]
+    const uint8_t *next; // [32][32]
+};
+
+// a pixel of the window or of its 3x3 stencils (x, y <= radius + 1): always inside the cached corner when the planes hold it
+__device__ __forceinline__ int pix(const uint8_t *cached, int dim, const CornerLevel &L, int x, int y, int &miss)
 {
     const bool inside = x >= 0 && x < L.w && y >= 0 && y < L.h;
     const bool in = inside && y < L.row_end && x < L.col_end;
     miss |= (inside && !in) ? 1 : 0;
-    const int cx = min(max(x, 0), min(L.w, L.col_end) - 1), cy = min(max(y, 0), min(L.h, L.row_end) - 1);
-    const int v = (int)img[(size_t)cy * (size_t)L.pitch + cx];
+    const int cx = min(max(x, 0), dim - 1), cy = min(max(y, 0), dim - 1);
+    const int v = (int)cached[cy * dim + cx];
     return in ? v : 0;
 }
 
 // cpu::shift_back_pyramid on channel 0 for one pixel (same rule as shift_1ch_kernel in pyramid.hip)
-__device__ __forceinline__ int shifted_next(const CornerLevel &L, int x, int y, bool shifted, float u, float v, int &miss)
+__device__ __forceinline__ int shifted_next(const CornerCache &C, const CornerLevel &L, int x, int y, bool shifted, float u, float v,
+                                            int &miss)
 {
     const bool inside = x >= 0 && x < L.w && y >= 0 && y < L.h;
-    const int own = pix(L.next, L, x, y, miss);
+    const int own = pix(C.next, kCornerNextDim, L, x, y, miss);
     const float ty = (float)y + v, tx = (float)x + u;
     const bool yin = ty > -1.0f && ty < (float)L.h;
     const int ny = yin ? (int)ty : 0;
@@ -45,20 +60,72 @@ __device__ __forceinline__ int shifted_next(const CornerLevel &L, int x, int y, 
     const int tnx = target ? (int)tx : 0;
     const bool hit = target && ny < L.row_end && tnx < L.col_end;
     miss |= (inside && target && !hit) ? 1 : 0;
-    const int nx = hit ? tnx : 0;
-    const int moved = (int)L.next[(size_t)(hit ? ny : 0) * (size_t)L.pitch + nx];
+    int moved = 0;
+    if (hit) {
+        if (tnx < kCornerNextDim && ny < kCornerNextDim)
+            moved = (int)C.next[ny * kCornerNextDim + tnx];
+        else
+            moved = (int)L.next[(size_t)ny * (size_t)L.pitch + tnx]; // far shift: outside the cached corner
+    }
     const bool keep = 3ll * ((long long)y * L.w + x) < (long long)L.w * (long long)L.h;
     const int val = !shifted ? own : (hit ? moved : (keep ? own : 0));
     return inside ? val : 0;
 }
 
-// One wave walks the pyramid coarse to fine.  f0 = 2*OFX_MAX_LEVELS floats of LDS private to this wave (the corner
-// flows found so far); only wave-level ordering is needed, so the function can run inside a larger workgroup.
-template <int MODE>
-__device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float *f0)
+// Copies the corners of every level into `cache` (levels * kCornerCacheBytes bytes of LDS private to this wave).  Rows
+// and dwords outside the planes are stored as zero (they are never selected: pix() tests the extents).
+__device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, uint8_t *cache)
 {
+    // Phase 1 issues every load of every level (branch-free: address clamped into the planes); phase 2, behind a
+    // scheduling barrier, masks the values and stores them.  Without the split hipcc puts a wait behind each load.
+    uint32_t pv[OFX_MAX_LEVELS], nv[OFX_MAX_LEVELS][4];
+#pragma unroll
+    for (int k = 0; k < OFX_MAX_LEVELS; ++k) {
+        pv[k] = nv[k][0] = nv[k][1] = nv[k][2] = nv[k][3] = 0u;
+        if (k >= A.levels) continue; // uniform
+        const CornerLevel &L = A.lv[k];
+        const int rows = min(L.h, L.row_end), last_c = L.pitch - 4;
+        pv[k] = *reinterpret_cast<const uint32_t *>(L.prev + (size_t)min(lane >> 2, rows - 1) * (size_t)L.pitch + min((lane & 3) * 4, last_c));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { // 32 rows x 8 dwords
+            const int idx = lane + 64 * i;
+            nv[k][i] = *reinterpret_cast<const uint32_t *>(L.next + (size_t)min(idx >> 3, rows - 1) * (size_t)L.pitch + min((idx & 7) * 4, last_c));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < OFX_MAX_LEVELS; ++k) {
+        if (k >= A.levels) continue;
+        const CornerLevel &L = A.lv[k];
+        const int rows = min(L.h, L.row_end), last_c = L.pitch - 4;
+        uint8_t *pc = cache + k * kCornerCacheBytes, *nc = pc + kCornerPrevDim * kCornerPrevDim;
+        {
+            const int r = lane >> 2, c = (lane & 3) * 4; // 16 rows x 4 dwords
+            *reinterpret_cast<uint32_t *>(pc + r * kCornerPrevDim + c) = (r < rows && c <= last_c) ? pv[k] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lane + 64 * i, r = idx >> 3, c = (idx & 7) * 4;
+            *reinterpret_cast<uint32_t *>(nc + r * kCornerNextDim + c) = (r < rows && c <= last_c) ? nv[k][i] : 0u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One wave walks the pyramid coarse to fine.  LDS private to this wave: f0 = 2*OFX_MAX_LEVELS floats (the corner flows
+// found so far) and cache = kCornerTileBytes + levels * kCornerCacheBytes bytes (two resolved tiles, then corner_prefetch's
+// corners).  Only wave-level ordering is needed, so the
+// function can run inside a larger workgroup.
+template <int MODE>
+__device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float *f0, uint8_t *cache)
+{
+    uint8_t *tileP = cache, *tileQ = cache + kCornerPrevDim * kCornerPrevDim;
+    cache += kCornerTileBytes;
+    corner_prefetch(A, lane, cache);
     for (int k = A.levels - 1; k >= 0; --k) {
         const CornerLevel &L = A.lv[k];
+        const CornerCache C{cache + k * kCornerCacheBytes, cache + k * kCornerCacheBytes + kCornerPrevDim * kCornerPrevDim};
         // shift vector: float accumulation, coarsest level first (OptFlowCPU.cpp:257-266)
         float u = 0.0f, v = 0.0f;
         for (int j = A.levels - 1; j > k; --j) {
@@ -71,9 +138,22 @@ __device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float
             A.uv[2 * k] = u;
             A.uv[2 * k + 1] = v;
         }
-        // window of pixel 0, clipped to the image: taps [0..R] x [0..R]
+        // Stage 1: every pixel the window's 3x3 stencils can touch -- x, y in [-1, radius+1] -- is resolved ONCE (border
+        // rule, shift, patch extents) into two small LDS tiles, prev and shifted next, indexed by coordinate + 1.  A lone wave
+        // issues an instruction every ~6 cycles, so the chain is bound by its instruction count: resolving the 9 neighbours
+        // inside every tap cost ~1.7k instructions per level, this costs ~0.4k.
+        const int rdim = A.radius + 3; // <= 16
+        int miss = 0;
+        for (int i = lane; i < rdim * rdim; i += 64) {
+            const int rx = i % rdim, ry = i / rdim;
+            tileP[ry * kCornerPrevDim + rx] = (uint8_t)pix(C.prev, kCornerPrevDim, L, rx - 1, ry - 1, miss);
+            tileQ[ry * kCornerPrevDim + rx] = (uint8_t)shifted_next(C, L, rx - 1, ry - 1, shifted, u, v, miss);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // Stage 2: window of pixel 0, clipped to the image: taps [0..R] x [0..R]
         const int tw = min(A.radius + 1, L.w), th = min(A.radius + 1, L.h);
-        int sxx = 0, syy = 0, sxy = 0, sxt = 0, syt = 0, miss = 0;
+        int sxx = 0, syy = 0, sxy = 0, sxt = 0, syt = 0;
         for (int t = lane; t < tw * th; t += 64) {
             const int x = t % tw, y = t / tw;
             int p[3][3], q[3][3];
@@ -81,8 +161,8 @@ __device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    p[i][j] = pix(L.prev, L, x - 1 + j, y - 1 + i, miss);
-                    q[i][j] = shifted_next(L, x - 1 + j, y - 1 + i, shifted, u, v, miss);
+                    p[i][j] = tileP[(y + i) * kCornerPrevDim + x + j]; // pixel (x - 1 + j, y - 1 + i)
+                    q[i][j] = tileQ[(y + i) * kCornerPrevDim + x + j];
                 }
             int ix = (p[0][2] + 2 * p[1][2] + p[2][2]) - (p[0][0] + 2 * p[1][0] + p[2][0]); // Dx_3x3, kernels.cpp:6-10
             int iy = (p[2][0] + 2 * p[2][1] + p[2][2]) - (p[0][0] + 2 * p[0][1] + p[0][2]); // Dy_3x3, kernels.cpp:15-19

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 // streams; the small latency-bound stages run in the shadow of the VALU-bound LK stage.  Blocks are 256 threads; an LK
 // block is four independent LK waves; the corner block runs one wave per pair.
 constexpr int kPyrStages = 2 * OFX_STREAM_MAX_BATCH; // per frame of the tick: its pyramid and its top-left patch pyramid
+constexpr int kCornerScratch = 128;                  // LDS of a corner block: the chain's floats, then the cached corners
 struct StreamArgs {
     LkTable lk;
     PyrArgs pyr[kPyrStages];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (b < OFX_STREAM_MAX_BATCH) {
         // one corner chain per block (wave 0), so that the chains land on different CUs
-        if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds));
+        if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
     } else if (b < S.first[0]) {
         lk_wave<R, MODE, false, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
     } else {
@@ -174,7 +175,11 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
     S.first[0] = OFX_STREAM_MAX_BATCH + lk_blocks;
     for (int i = 0; i < kPyrStages; ++i) S.first[i + 1] = S.first[i] + stage_blocks[i];
     const int blocks = S.first[kPyrStages];
-    const size_t corner_lds = (size_t)2 * OFX_MAX_LEVELS * sizeof(float); // a corner wave's scratch
+    size_t corner_lds = 0; // a corner wave's scratch: the chain's floats and the cached corners of its levels
+    for (int i = 0; i < S.n_corner; ++i) {
+        const size_t need = (size_t)kCornerScratch + kCornerTileBytes + (size_t)S.corner[i].levels * kCornerCacheBytes;
+        corner_lds = need > corner_lds ? need : corner_lds;
+    }
     if (lds < corner_lds) lds = corner_lds;
     hipLaunchKernelGGL((stream_kernel<R, MODE>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
