@@ -160,7 +160,8 @@ def test_pair_golden_compat_cpu(eng, golden):
         assert_same(one, g[tag + "_flow_single"], "single level " + tag)
 
 
-@pytest.mark.parametrize("cfg", [(640, 480, 3, 5), (320, 240, 4, 19), (256, 192, 3, 9)])
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 5), (320, 240, 4, 19), (256, 192, 3, 9), (250, 186, 2, 7), (1002, 50, 2, 5), (6, 4, 2, 3),
+                                 (516, 260, 3, 9)])  # the last four: widths that are not a multiple of 4 / 64 / 240 at some level
 @pytest.mark.parametrize("mode", ["compat_cpu", "lk_float"])
 def test_pair_vs_oracle(eng, oracle, cfg, mode):
     w, h, levels, win = cfg  # first entry is BASELINE config[0]: 640x480, 3 levels, 5x5
@@ -295,7 +296,8 @@ def test_pipelined_submit_equals_plain_sequence(eng, mode):
     piped.close()
 
 
-@pytest.mark.parametrize("cfg", [(512, 384, 4, 9, "lk_float"), (512, 384, 4, 9, "compat_cpu"), (320, 200, 3, 15, "lk_float"), (64, 32, 2, 3, "lk_float")])
+@pytest.mark.parametrize("cfg", [(512, 384, 4, 9, "lk_float"), (512, 384, 4, 9, "compat_cpu"), (320, 200, 3, 15, "lk_float"), (64, 32, 2, 3, "lk_float"),
+                                 (250, 186, 2, 7, "lk_float"), (516, 260, 3, 9, "compat_cpu")])
 def test_stream_pipeline_equals_plain_sequence(eng, cfg):
     """The one-launch-per-frame stream pipeline (pyramid | corner | shift | LK of four consecutive pairs side by side in one
     grid) must reproduce, pair by pair, the bits of the plain sequence; pair p's flow appears with frame p+2."""
@@ -303,7 +305,14 @@ def test_stream_pipeline_equals_plain_sequence(eng, cfg):
 
     w, h, L, win, mode = cfg
     nf = 9
-    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=31)[1]).cuda() for i in range(nf)]
+    # frames live in padded buffers (row pitch != width; the stream path needs a pitch that is a multiple of 4, dirty padding
+    # bytes must not leak into the result)
+    pitch = (w + 3) // 4 * 4 + 4
+    def padded(a):
+        buf = torch.full((h, pitch), 0xA5, dtype=torch.uint8, device="cuda")
+        buf[:, :w] = torch.from_numpy(a).cuda()
+        return buf[:, :w]
+    frames = [padded(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=31)[1]) for i in range(nf)]
     plain = eng.Session(w, h, L, win, mode)
     plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
     want = {}
