@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=2, choices=[1, 2],
+    ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 4],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
@@ -133,7 +133,7 @@ def main():
             # one launch per frame: pyramid(frame j) | corner(pair j-1) | fused LK(pair j-2, global shift in its loads) side by side in
             # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
             sess.stream_begin()
-            for i in range(6):
+            for i in range(12):
                 sess.stream_submit(d_frames[i % nframes])
 
             def step(i):
@@ -162,7 +162,7 @@ def main():
         sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
-            for i in range(6):
+            for i in range(12):
                 driver.stream_submit(d_frames[i % nframes])
 
             def step(i):

@@ -24,8 +24,8 @@ struct LkArgs {
 
 // one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
 struct LkTable {
-    LkArgs lv[OFX_MAX_LEVELS];
-    int first_block[OFX_MAX_LEVELS + 1];
+    LkArgs lv[OFX_MAX_LK_ITEMS];
+    int first_block[OFX_MAX_LK_ITEMS + 1];
     int n;
 };
 

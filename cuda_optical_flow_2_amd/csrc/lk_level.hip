@@ -164,7 +164,7 @@ template <int R, int MODE>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
-    // carries two (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
+    // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
     static const int capacity1 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 2);
     static const int capacity2 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 4);
     int pairs = 0;
@@ -236,7 +236,7 @@ int launch_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
 
 int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, LkLevelIn *lv, int *count)
 {
-    OFX_REQUIRE(d != nullptr && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_lk_levels: bad descriptor count %d", n);
+    OFX_REQUIRE(d != nullptr && n >= 1 && n <= OFX_MAX_LK_ITEMS, "ofx_lk_levels: bad descriptor count %d", n);
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_lk_level: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_lk_level: bad mode %d", mode);
     const int radius = window >> 1;
@@ -277,7 +277,7 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
 
 int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, void *stream)
 {
-    LkLevelIn lv[OFX_MAX_LEVELS];
+    LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;
     OFX_TRY(lk_build_levels(d, n, window, mode, d_sums, lv, &m));
     if (m == 0) return OFX_OK;
@@ -332,7 +332,7 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &S.corner[i]));
     }
     S.n_corner = g->n_corner;
-    LkLevelIn lv[OFX_MAX_LEVELS];
+    LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;
     if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;

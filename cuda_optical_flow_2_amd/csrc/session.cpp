@@ -13,8 +13,11 @@
 
 namespace {
 constexpr size_t kAlign = 256;
-constexpr int kSets = 8;    // image sets: 3 rotate in the pair-at-a-time paths; the stream pipeline uses 5 (one frame per tick) or 8 (two)
-constexpr int kUvSlots = 4; // shift-vector slots: 2 alternate per pair, the two-frame stream tick needs 4
+// The stream pipeline with B frames per tick uses 3B + 2 image sets and 2B shift-vector slots (see stream_tick); the
+// pair-at-a-time paths rotate 3 sets and alternate 2 slots.
+constexpr int kMaxBatch = OFX_STREAM_MAX_BATCH;
+constexpr int kSets = 3 * kMaxBatch + 2;
+constexpr int kUvSlots = 2 * kMaxBatch;
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 } // namespace
 
@@ -46,9 +49,10 @@ struct ofx_session {
     int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
     int *corner_status = nullptr;
     float *flow[OFX_MAX_LEVELS]{};       // where results are read from: flowset[0], or the newest pair's set in a two-frame stream
-    float *flowset[2][OFX_MAX_LEVELS]{}; // pair p's flow goes to set p & 1 when stream_batch == 2 (one set otherwise)
-    const uint8_t *held_frame = nullptr; // two-frame stream tick: the even frame waiting for its partner
-    int held_pitch = 0;
+    float *flowset[kMaxBatch][OFX_MAX_LEVELS]{}; // stream pipeline: pair p's flow goes to set p mod stream_batch
+    const uint8_t *held_frame[kMaxBatch]{};      // multi-frame stream tick: the frames waiting for the tick to fill
+    int held_pitch[kMaxBatch]{};
+    int n_held = 0;
     long reported = 0;                   // highest pair reported complete by the stream pipeline
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
@@ -91,10 +95,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(p->window >= 3 && (p->window & 1), "ofx_session_create: window must be odd and >= 3");
     OFX_REQUIRE(p->mode == OFX_MODE_COMPAT_CPU || p->mode == OFX_MODE_LK_FLOAT, "ofx_session_create: bad mode %d", p->mode);
     OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
-    OFX_REQUIRE(p->stream_batch >= 0 && p->stream_batch <= OFX_STREAM_MAX_BATCH, "ofx_session_create: stream_batch %d out of range",
-                p->stream_batch);
-    OFX_REQUIRE(p->stream_batch < 2 || 2 * p->levels <= OFX_MAX_LEVELS, "ofx_session_create: stream_batch 2 needs levels <= %d",
-                OFX_MAX_LEVELS / 2);
+    OFX_REQUIRE(p->stream_batch == 0 || p->stream_batch == 1 || p->stream_batch == 2 || p->stream_batch == 4,
+                "ofx_session_create: stream_batch %d (0, 1, 2 or 4)", p->stream_batch);
+    OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
+                p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
     OFX_REQUIRE(p->iters <= 1 || (p->mode == OFX_MODE_LK_FLOAT && !p->sharded),
                 "ofx_session_create: refinement iterations need mode lk_float and an unsharded session");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
@@ -110,7 +114,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(s != nullptr, "ofx_session_create: out of host memory");
     s->p = *p;
     size_t total = 0;
-    std::vector<size_t> off_plane[kSets + 2], off_flow, off_flow2;
+    std::vector<size_t> off_plane[kSets + 2], off_flow, off_flow2, flow_stride;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
         s->h[k] = p->height >> k;
@@ -146,8 +150,9 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         const size_t own_rows = (size_t)(s->own1[k] - s->own0[k]);
         const size_t flow_bytes = align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
         total += flow_bytes;
-        off_flow2.push_back(total); // second flow set: a two-frame stream tick writes the flows of two pairs
-        if (p->stream_batch >= 2) total += flow_bytes;
+        off_flow2.push_back(total); // further flow sets: a B-frame stream tick writes the flows of B pairs
+        if (p->stream_batch >= 2) total += flow_bytes * (size_t)(p->stream_batch - 1);
+        flow_stride.push_back(flow_bytes);
     }
     std::vector<size_t> off_patch[kSets];
     if (p->local_corner) {
@@ -201,7 +206,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         for (int t = 0; t < kSets; ++t) s->img[t][k] = base + off_plane[t][k];
         for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[kSets + t][k];
         s->flowset[0][k] = reinterpret_cast<float *>(base + off_flow[k]);
-        s->flowset[1][k] = reinterpret_cast<float *>(base + (p->stream_batch >= 2 ? off_flow2[k] : off_flow[k]));
+        for (int t = 1; t < kMaxBatch; ++t)
+            s->flowset[t][k] = reinterpret_cast<float *>(base + (t < p->stream_batch ? off_flow2[k] + (size_t)(t - 1) * flow_stride[k] : off_flow[k]));
         s->flow[k] = s->flowset[0][k];
     }
     if (p->local_corner)
@@ -627,23 +633,27 @@ extern "C" int ofx_session_corner_status(ofx_session *s, int *h_status, void *st
 }
 
 // ---- stream pipeline: one launch per tick of B frames ----------------------------------------------------------------
-// Frame f (0-based) belongs to tick f / B (B = stream_batch, 1 or 2).  Pair p is (frame p-1 -> frame p).  The tick whose
-// first frame is f0 runs, side by side in one grid,
+// Frame f (0-based) belongs to tick f / B (B = stream_batch: 1, 2 or 4).  Pair p is (frame p-1 -> frame p).  The tick
+// whose first frame is f0 runs, side by side in one grid,
 //     pyramid(frames f0 .. f0+B-1) | corner(pairs f0-B .. f0-1) | LK(pairs f0-2B .. f0-B-1, shift fused)
 // so every stage consumes what earlier ticks wrote and the ticks are ordered by the stream.  Frame f lives in image set
-// f mod S and pair p's shift vectors in slot p mod U (B = 1: S = 5, U = 2; B = 2: S = 8, U = 4): a set is last read by
-// LK(pair f+1), one or two ticks before it is rewritten; a slot is read by LK(pair p) a tick before pair p+U's corner
-// stage rewrites it.  With B = 2 the flows of pair p go to flow set p & 1.  After a tick every pair <= f0-B-1 is done.
+// f mod (3B+2) and pair p's shift vectors in slot p mod 2B: a set is last read by LK(pair f+1), at the latest in the tick
+// that starts with frame f+2B+1, and rewritten by the tick that holds frame f+3B+2; a slot is read by LK(pair p) one tick
+// after the corner stage wrote it and rewritten two ticks after.  The flows of pair p go to flow set p mod B.  After a
+// tick every pair <= f0-B-1 is done.
+static int stream_batch_of(const ofx_session *s) { return s->p.stream_batch >= 2 ? s->p.stream_batch : 1; }
+
 static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *pitches, int n_frames, void *stream, int *completed_pair)
 {
-    const int B = s->p.stream_batch >= 2 ? 2 : 1;
-    const int sets = B == 2 ? 8 : 5, slots = B == 2 ? 4 : 2;
+    const int B = stream_batch_of(s);
+    const int sets = 3 * B + 2, slots = 2 * B;
     const long f0 = s->stream_n; // index of the first frame of this tick
     const int L = s->p.levels;
     auto uvslot = [&](long pair) { return s->uv + (size_t)(pair % slots) * 2 * OFX_MAX_LEVELS; };
     auto set_of = [&](long frame) { return (int)(frame % sets); };
     const long last_frame = s->stream_frames >= 0 ? s->stream_frames - 1 : f0 + n_frames - 1;
-    ofx_stream_stages g;
+    // the stages struct is several KB: keep it off the stack of callers with small stacks
+    static thread_local ofx_stream_stages g;
     memset(&g, 0, sizeof g);
     for (int i = 0; i < n_frames; ++i) { // pyramid(frame f0 + i)
         OFX_REQUIRE(pitches[i] >= s->w[0] && (pitches[i] & 3) == 0 && ((uintptr_t)frames[i] & 3) == 0,
@@ -691,7 +701,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     long newest = -1;
     for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
         if (pl < 1 || pl > last_frame) continue;
-        float *const *fl = s->flowset[B == 2 ? (pl & 1) : 0];
+        float *const *fl = s->flowset[pl % B];
         for (int k = L - 1; k >= 0; --k)
             g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, s->own0[k], s->own1[k]),
                                          fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0};
@@ -701,7 +711,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     if (newest > s->reported) {
         *completed_pair = (int)newest;
         s->reported = newest;
-        for (int k = 0; k < L; ++k) s->flow[k] = s->flowset[B == 2 ? (newest & 1) : 0][k];
+        for (int k = 0; k < L; ++k) s->flow[k] = s->flowset[newest % B][k];
     }
     static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }(); // timing experiments only
     if (skip & 1) g.n_pyr = 0;
@@ -728,7 +738,7 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
     OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
     s->stream_n = 0;
     s->stream_frames = -1;
-    s->held_frame = nullptr;
+    s->n_held = 0;
     s->reported = 0;
     s->have_prev = s->have_next = s->staged = false;
     for (int k = 0; k < s->p.levels; ++k) s->flow[k] = s->flowset[0][k];
@@ -747,27 +757,25 @@ extern "C" int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1,
     OFX_REQUIRE(s->stream_frames < 0, "ofx_session_stream_submit: the stream is being drained");
     int dummy = -1;
     if (!completed_pair) completed_pair = &dummy;
-    if (s->p.stream_batch >= 2 && s->held_frame == nullptr) { // first frame of a two-frame tick: wait for its partner
-        s->held_frame = d_gray1;
-        s->held_pitch = pitch;
+    const int B = stream_batch_of(s);
+    if (s->n_held + 1 < B) { // the tick is not full yet: remember the frame
+        s->held_frame[s->n_held] = d_gray1;
+        s->held_pitch[s->n_held] = pitch;
+        ++s->n_held;
         *completed_pair = -1;
         return OFX_OK;
     }
-    const uint8_t *fr[2] = {d_gray1, nullptr};
-    int pt[2] = {pitch, 0};
-    int n = 1;
-    if (s->held_frame) {
-        fr[0] = s->held_frame;
-        pt[0] = s->held_pitch;
-        fr[1] = d_gray1;
-        pt[1] = pitch;
-        n = 2;
-        s->held_frame = nullptr;
-    }
+    const uint8_t *fr[kMaxBatch];
+    int pt[kMaxBatch];
+    for (int i = 0; i < s->n_held; ++i) fr[i] = s->held_frame[i], pt[i] = s->held_pitch[i];
+    fr[s->n_held] = d_gray1;
+    pt[s->n_held] = pitch;
+    const int n = s->n_held + 1;
+    s->n_held = 0;
     return stream_tick(s, fr, pt, n, stream, completed_pair);
 }
 
-// Run one more tick without a new frame (a frame still waiting for its partner goes out with it); call until it
+// Run one more tick without a new frame (frames still waiting for their tick to fill go out with it); call until it
 // reports -2 in *completed_pair (pipeline empty).  Two ticks drain a full pipeline.
 extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair)
 {
@@ -776,13 +784,12 @@ extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *compl
         ofx_set_error("ofx_session_stream_drain: not streaming");
         return OFX_E_STATE;
     }
-    const int B = s->p.stream_batch >= 2 ? 2 : 1;
-    const uint8_t *fr[2] = {s->held_frame, nullptr};
-    int pt[2] = {s->held_pitch, 0};
-    const int n = s->held_frame ? 1 : 0;
-    s->held_frame = nullptr;
+    const uint8_t *fr[kMaxBatch];
+    int pt[kMaxBatch];
+    const int n = s->n_held;
+    for (int i = 0; i < n; ++i) fr[i] = s->held_frame[i], pt[i] = s->held_pitch[i];
+    s->n_held = 0;
     if (s->stream_frames < 0) s->stream_frames = s->stream_n + n; // number of frames the stream received
-    (void)B;
     if (n == 0 && s->reported >= s->stream_frames - 1) { // every pair (the last one is stream_frames - 1) has been reported
         *completed_pair = -2;
         s->stream_n = -1;
@@ -795,10 +802,10 @@ extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *compl
 extern "C" int ofx_session_flow_of(ofx_session *s, int pair, int level, float **d_ptr, int *row0, int *rows)
 {
     OFX_REQUIRE(s && level >= 0 && level < s->p.levels, "ofx_session_flow_of: bad arguments");
-    const int B = s->p.stream_batch >= 2 ? 2 : 1;
+    const int B = stream_batch_of(s);
     OFX_REQUIRE(pair >= 1 && pair <= s->reported && pair > s->reported - B,
                 "ofx_session_flow_of: pair %d is not among the newest %d completed pairs (newest: %ld)", pair, B, s->reported);
-    if (d_ptr) *d_ptr = s->flowset[B == 2 ? (pair & 1) : 0][level];
+    if (d_ptr) *d_ptr = s->flowset[pair % B][level];
     if (row0) *row0 = s->own0[level];
     if (rows) *rows = s->own1[level] - s->own0[level];
     return OFX_OK;

@@ -45,6 +45,7 @@ extern "C" {
                                  double solve */
 
 #define OFX_MAX_LEVELS 12
+#define OFX_MAX_LK_ITEMS 24 /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
 
 const char *ofx_last_error(void);
 /* library/ABI version, bumped when a signature changes */
@@ -109,10 +110,11 @@ typedef struct ofx_shift_desc {
 /* One tick of the frame-stream pipeline in ONE launch: the pyramids of the newest frame(s) | the corner flows of earlier
  * pair(s) | the fused LK of still earlier pair(s), as disjoint block ranges of one grid.  Every stage only reads what
  * earlier launches wrote, so the stages need no synchronisation; a stage is skipped when its count is 0.  A tick may
- * carry up to OFX_STREAM_MAX_BATCH frames / pairs per stage (ofx_params.stream_batch): the LK items of two pairs then
- * share one launch, which doubles the strip height (half the priming rows per output row) and halves the launches.
+ * carry up to OFX_STREAM_MAX_BATCH frames / pairs per stage (ofx_params.stream_batch): the LK items of B pairs then
+ * share one launch, which multiplies the strip height by B (1/B of the priming rows per output row) and divides the
+ * number of launches by B.
  * ofx_session_stream_submit drives this; it is exposed for callers that manage their own buffers. */
-#define OFX_STREAM_MAX_BATCH 2
+#define OFX_STREAM_MAX_BATCH 4
 typedef struct ofx_pyramid_stage {
     /* levels 1..levels-1 from d_frame, plus a copy of level 0 into d_levels[0] */
     const uint8_t *d_frame;
@@ -146,7 +148,7 @@ typedef struct ofx_stream_stages {
     int n_pyr;
     ofx_corner_stage corner[OFX_STREAM_MAX_BATCH];
     int n_corner;
-    ofx_lk_desc lk[OFX_MAX_LEVELS]; /* the LK items of every pair of the tick (levels x pairs <= OFX_MAX_LEVELS) */
+    ofx_lk_desc lk[OFX_MAX_LK_ITEMS]; /* the LK items of every pair of the tick (levels x pairs <= OFX_MAX_LK_ITEMS) */
     int n_lk;
 } ofx_stream_stages;
 int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
@@ -289,8 +291,8 @@ typedef struct ofx_params {
      * the patch; ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
-    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 = one launch per two frames (see
-     * ofx_session_stream_submit). */
+    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 = one launch per two / four frames
+     * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
     int reserved[4];
 } ofx_params;
@@ -332,20 +334,20 @@ int ofx_session_stage_shift(ofx_session *s, void *aux_stream);
 int ofx_session_solve_staged(ofx_session *s, void *stream);
 int ofx_session_aux_stream(ofx_session *s, void **stream);
 /* Stream pipeline (highest throughput): ONE launch (ofx_stream_launch) per tick of B = ofx_params.stream_batch frames
- * (1 or 2), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
+ * (1, 2 or 4), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
  * included) of the B pairs before that run side by side.  With B = 1 every call launches and the flow of pair p (frame
- * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  With B = 2 a call with an even frame
- * index only remembers the frame (its buffer must stay unmodified until the next call has returned) and the next call
- * launches for both; pairs complete two at a time, one tick later.  *completed_pair receives the HIGHEST pair complete
- * after the call in `stream` order (all lower ones are complete too; -1 while the pipeline fills); the flows of the
- * newest B pairs are at ofx_session_flow_of.  After the last frame call ofx_session_stream_drain until it reports -2.
- * Results are bit-identical to the pair-at-a-time paths.  A frame buffer must stay valid until the launch that
- * received it has finished. */
+ * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  With B > 1 only every B-th call launches,
+ * for the B frames received since the last launch (the others are remembered: their buffers must stay unmodified until
+ * that launching call has returned); pairs complete B at a time, one tick later.  *completed_pair receives the HIGHEST
+ * pair complete after the call in `stream` order (all lower ones are complete too; -1 when the call completed none); the
+ * flows of the newest B pairs are at ofx_session_flow_of.  After the last frame call ofx_session_stream_drain until it
+ * reports -2.  Results are bit-identical to the pair-at-a-time paths.  A frame buffer must stay valid until the launch
+ * that received it has finished. */
 int ofx_session_stream_begin(ofx_session *s);
 int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair);
 int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair);
-/* Flow of `pair` at `level` while it is one of the newest stream_batch completed pairs of the stream pipeline (pairs
- * alternate between two flow sets when stream_batch == 2).  Same outputs as ofx_session_flow. */
+/* Flow of `pair` at `level` while it is one of the newest stream_batch completed pairs of the stream pipeline (pair p
+ * lives in flow set p mod stream_batch).  Same outputs as ofx_session_flow. */
 int ofx_session_flow_of(ofx_session *s, int pair, int level, float **d_ptr, int *row0, int *rows);
 /* prev <- next (main.cu:270-272). */
 int ofx_session_swap(ofx_session *s);

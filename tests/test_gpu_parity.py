@@ -444,18 +444,20 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 
+@pytest.mark.parametrize("batch", [2, 4])
 @pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
-                                 (640, 480, 6, 9, "lk_float", 1, 8)])
-def test_two_frame_stream_ticks_equal_plain_sequence(eng, cfg):
-    """ofx_params.stream_batch = 2: one launch per TWO frames (the LK items of two pairs share a launch: taller strips,
-    half the launches).  Calls with an even frame index only remember the frame; pairs complete two at a time and are
-    read through ofx_session_flow_of.  Every pair must carry the bits of the plain sequence -- also for row-sharded
-    sessions with local corner flows (third config: 4 logical ranks) and for odd frame counts (the last frame goes out
-    alone when the stream is drained)."""
+                                 (640, 480, 6, 9, "lk_float", 1, 14)])
+def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch):
+    """ofx_params.stream_batch = B: one launch per B frames (the LK items of B pairs share a launch: taller strips, 1/B of
+    the launches).  Only every B-th call launches; pairs complete B at a time and are read through ofx_session_flow_of.
+    Every pair must carry the bits of the plain sequence -- also for row-sharded sessions with local corner flows (third
+    config: 4 logical ranks) and for frame counts that are not a multiple of B (the tail goes out when the stream is
+    drained)."""
     import torch
     from cuda_optical_flow_2_amd.parallel import ShardPlan
 
     w, h, L, win, mode, R, nf = cfg
+    B = batch
     frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.2 * i, -0.6 * i, seed=41)[1]).cuda() for i in range(nf)]
     plain = eng.Session(w, h, L, win, mode)
     plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
@@ -468,9 +470,9 @@ def test_two_frame_stream_ticks_equal_plain_sequence(eng, cfg):
     plain.close()
 
     if R == 1:
-        ranks = [eng.Session(w, h, L, win, mode, stream_batch=2)]
+        ranks = [eng.Session(w, h, L, win, mode, stream_batch=B)]
     else:
-        ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=2) for r in range(R)]
+        ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B) for r in range(R)]
     got = {}
     for s in ranks:
         s.stream_begin()
@@ -478,14 +480,14 @@ def test_two_frame_stream_ticks_equal_plain_sequence(eng, cfg):
     def snap(done):
         nonlocal seen
         if done >= 1:
-            for p in range(max(seen + 1, done - 1), done + 1):   # the newest two pairs are readable
+            assert done - seen <= B
+            for p in range(max(seen + 1, done - B + 1), done + 1):   # the newest B pairs are readable
                 got[p] = [[s.flow_of(p, k)[0].clone() for k in range(L)] for s in ranks]
-            assert done - seen <= 2
             seen = done
     for i in range(nf):
         dones = [s.stream_submit(frames[i]) for s in ranks]
         assert len(set(dones)) == 1
-        if i % 2 == 0:
+        if i % B != B - 1:
             assert dones[0] == -1   # the frame is only remembered
         snap(dones[0])
     while True:

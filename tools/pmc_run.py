@@ -9,7 +9,7 @@ cfg = {"4k": (3840, 2160, 5, 9), "1080p": (1920, 1080, 4, 7), "8k": (7680, 4320,
 path = sys.argv[2] if len(sys.argv) > 2 else "plain"
 w, h, L, win = cfg
 p, n = synth.smooth_pair(w, h)
-s = engine.Session(w, h, L, win, "lk_float", stream_batch=2 if path == "stream" else 1)  # as bench.py's defaults
+s = engine.Session(w, h, L, win, "lk_float", stream_batch=4 if path == "stream" else 1)  # as bench.py runs it
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     if path == "plain":
@@ -20,7 +20,7 @@ with torch.cuda.stream(st):
     else:
         frames = [torch.from_numpy(x).cuda() for x in (p, n)]
         s.stream_begin()
-        for i in range(20):
+        for i in range(40):
             s.stream_submit(frames[i & 1])
 torch.cuda.synchronize()
 s.close()

@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_e
+O=$R/gpurun_out/prof_f
 rm -rf $O; mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -- python bench.py --no-cpu-baseline > $O/bench_stream.json 2> $O/stream.err
@@ -13,7 +13,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_plain -- python t
 mkdir -p $O/pmc_stream $O/pmc_plain
 cp -r $O/pmc_fetch_stream $O/pmc_write_stream $O/pmc_stream/
 cp -r $O/pmc_fetch_plain $O/pmc_write_plain $O/pmc_plain/
-python tools/pmc_parse.py $O/pmc_stream stream_kernel 4 > $O/traffic_stream.json
+python tools/pmc_parse.py $O/pmc_stream stream_kernel 3 > $O/traffic_stream.json
 python tools/pmc_parse.py $O/pmc_plain lk_level_kernel 1 > $O/traffic_plain.json
 cat $O/traffic_stream.json $O/traffic_plain.json
 find $O -name "*kernel_stats.csv" | head

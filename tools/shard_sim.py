@@ -1,6 +1,6 @@
 """What one rank of an N-rank row-sharded run costs, measured on ONE GPU: a sharded local-corner session for rank r of N
 running the stream pipeline alone (ranks share nothing on the data path, so this is the per-rank time of the real run).
-    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2: frames per launch, default 2)"""
+    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4: frames per launch, default 4)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,7 +18,7 @@ for N in worlds:
     res = []
     for r in sorted({0, N // 2, N - 1}):
         s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True,
-                           stream_batch=int(os.environ.get("OFX_SIM_BATCH", "2")))
+                           stream_batch=int(os.environ.get("OFX_SIM_BATCH", "4")))
         s.stream_begin()
         for i in range(20):
             s.stream_submit(frames[i % 4])
