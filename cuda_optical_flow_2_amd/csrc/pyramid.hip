@@ -183,16 +183,20 @@ int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t 
         a.h[k] = h >> k;
     }
     const int H0 = (1 << a.n) - 1;
-    // two LDS areas used alternately: even levels in area 0, odd levels in area 1
+    // Levels 1 .. n-1 live in LDS (level 0 is read from HBM directly, level n is only written out), in two areas used
+    // alternately: even levels in area 0, odd levels in area 1, each with 16 bytes of slack in front (a thread's leftmost
+    // source dword may start 4 bytes before its row).  Column of pixel x: x - X_k + delta[k], delta[n-1] = the halo of that
+    // level rounded up to 4, delta[k] = 2*delta[k+1]; a row holds delta + tile + 12 bytes (groups of 4 that reach past the tile).
     size_t area[2] = {0, 0};
-    for (int k = 1; k <= a.n; ++k) { // level 0 is read from HBM directly, levels 1..n live in LDS
-        const int r = (kPyrTile >> k) + (H0 >> k);
-        a.stride[k] = (r + 3) & ~3;
-        const size_t bytes = (size_t)a.stride[k] * (size_t)(r + 1);
+    for (int k = a.n - 1; k >= 1; --k) {
+        const int Hk = H0 >> k, Tk = kPyrTile >> k;
+        a.delta[k] = k == a.n - 1 ? ((Hk + 3) & ~3) : 2 * a.delta[k + 1];
+        a.stride[k] = (Tk + a.delta[k] + 12 + 3) & ~3;
+        const size_t bytes = 16 + (size_t)a.stride[k] * (size_t)(Tk + Hk + 1);
         if (bytes > area[k & 1]) area[k & 1] = bytes;
     }
     area[0] = (area[0] + 15) & ~(size_t)15;
-    for (int k = 0; k <= a.n; ++k) a.lds_off[k] = (k & 1) ? (int)area[0] : 0;
+    for (int k = 0; k <= a.n; ++k) a.lds_off[k] = 16 + ((k & 1) ? (int)area[0] : 0);
     *lds_bytes = area[0] + ((area[1] + 15) & ~(size_t)15);
     // destination row windows (row0 == NULL: whole levels).  The tiles launched are those that intersect any window,
     // expressed in level-0 rows: a level-k row y belongs to the tile row (y << k) / kPyrTile.

@@ -65,11 +65,27 @@ __device__ __forceinline__ void downsample_rows(const DownArgs &A, int c4 /* gro
     *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.dst_row0) * (size_t)A.dst_pitch + x0) = out;
 }
 
+// [1 2 1]^T [1 2 1] / 16 of three source rows for 4 destination pixels, SWAR on 16-bit halves: lo / hi = the 8 source bytes
+// at columns 2*x0 .. 2*x0+7 of each row, lf = the byte at column 2*x0-1.  A dword's even bytes (b0,b2) and odd bytes
+// (b1,b3) are summed down the rows (at most 1020), then out = left + 2*centre + right (at most 4080) >> 4: the same
+// integers as down4.
+__device__ __forceinline__ uint32_t gauss3_rows(uint32_t l0, uint32_t l1, uint32_t l2, uint32_t h0, uint32_t h1, uint32_t h2, uint32_t f0,
+                                                uint32_t f1, uint32_t f2)
+{
+    const uint32_t M = 0x00ff00ffu;
+    const uint32_t elo = (l0 & M) + 2u * (l1 & M) + (l2 & M), olo = ((l0 >> 8) & M) + 2u * ((l1 >> 8) & M) + ((l2 >> 8) & M);
+    const uint32_t ehi = (h0 & M) + 2u * (h1 & M) + (h2 & M), ohi = ((h0 >> 8) & M) + 2u * ((h1 >> 8) & M) + ((h2 >> 8) & M);
+    const uint32_t left = f0 + 2u * f1 + f2;
+    const uint32_t a = 2u * elo + olo + ((olo << 16) | left);        // destination pixels 0 (low half) and 1
+    const uint32_t b = 2u * ehi + ohi + ((olo >> 16) | (ohi << 16)); // destination pixels 2 and 3
+    return ((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8) | (((b >> 4) & 0xffu) << 16) | (((b >> 20) & 0xffu) << 24);
+}
+
 // Two vertically adjacent groups of 4 destination pixels (rows y and y+1, x0 a multiple of 4) from ONE set of loads:
 // source rows 2y-1 .. 2y+3, columns 2*x0-1 .. 2*x0+7 of a full-height source (rows [0,sh), columns [0,sw)).  All 15 loads
-// are issued before the first use.  The arithmetic is SWAR on 16-bit halves: a dword's even bytes (b0,b2) and odd bytes
-// (b1,b3) are summed down the 3 rows ([1 2 1], at most 1020), then out = left + 2*centre + right (at most 4080) >> 4:
-// the same integers as down4.
+// are issued before the first use.  INTERIOR: the caller guarantees that every source byte and both destination rows lie
+// inside the images (no guards, no masks).
+template <bool INTERIOR>
 __device__ __forceinline__ void down4x2(const uint8_t *src, int src_pitch, int sh, int sw, int dw, int dh, int x0, int y, uint32_t &out0,
                                         uint32_t &out1)
 {
@@ -78,41 +94,37 @@ __device__ __forceinline__ void down4x2(const uint8_t *src, int src_pitch, int s
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
         const int sy = 2 * y - 1 + p;
-        lo[p] = hi[p] = lf[p] = 0u;
-        if (sy >= 0 && sy < sh) {
-            const uint8_t *row = src + (size_t)sy * (size_t)src_pitch;
-            // the source pitch is a multiple of 4 and >= sw, so a dword starting below sw stays inside the row pitch
-            if (sx < sw) lo[p] = *reinterpret_cast<const uint32_t *>(row + sx);
-            if (sx + 4 < sw) hi[p] = *reinterpret_cast<const uint32_t *>(row + sx + 4);
-            if (sx > 0 && sx - 1 < sw) lf[p] = row[sx - 1];
+        if constexpr (INTERIOR) {
+            const uint8_t *row = src + (size_t)sy * (size_t)src_pitch + sx;
+            lo[p] = *reinterpret_cast<const uint32_t *>(row);
+            hi[p] = *reinterpret_cast<const uint32_t *>(row + 4);
+            lf[p] = *reinterpret_cast<const uint32_t *>(row - 4) >> 24;
+        } else {
+            lo[p] = hi[p] = lf[p] = 0u;
+            if (sy >= 0 && sy < sh) {
+                const uint8_t *row = src + (size_t)sy * (size_t)src_pitch;
+                // the source pitch is a multiple of 4 and >= sw, so a dword starting below sw stays inside the row pitch
+                if (sx < sw) lo[p] = *reinterpret_cast<const uint32_t *>(row + sx);
+                if (sx + 4 < sw) hi[p] = *reinterpret_cast<const uint32_t *>(row + sx + 4);
+                if (sx > 0 && sx - 1 < sw) lf[p] = row[sx - 1];
+            }
         }
     }
-    // bytes at columns >= sw (pitch padding) do not count
-    const uint32_t mlo = sx + 4 <= sw ? 0xffffffffu : (sx < sw ? 0xffffffffu >> (8 * (sx + 4 - sw)) : 0u);
-    const uint32_t mhi = sx + 8 <= sw ? 0xffffffffu : (sx + 4 < sw ? 0xffffffffu >> (8 * (sx + 8 - sw)) : 0u);
-    uint32_t out[2];
+    if constexpr (INTERIOR) {
+        out0 = gauss3_rows(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], lf[0], lf[1], lf[2]);
+        out1 = gauss3_rows(lo[2], lo[3], lo[4], hi[2], hi[3], hi[4], lf[2], lf[3], lf[4]);
+    } else {
+        // bytes at columns >= sw (pitch padding) do not count
+        const uint32_t mlo = sx + 4 <= sw ? 0xffffffffu : (sx < sw ? 0xffffffffu >> (8 * (sx + 4 - sw)) : 0u);
+        const uint32_t mhi = sx + 8 <= sw ? 0xffffffffu : (sx + 4 < sw ? 0xffffffffu >> (8 * (sx + 8 - sw)) : 0u);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        uint32_t elo = 0, olo = 0, ehi = 0, ohi = 0, left = 0;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int p = 2 * r + t;
-            const uint32_t wgt = t == 1 ? 2u : 1u;
-            const uint32_t l = lo[p] & mlo, h = hi[p] & mhi;
-            elo += wgt * (l & 0x00ff00ffu);
-            olo += wgt * ((l >> 8) & 0x00ff00ffu);
-            ehi += wgt * (h & 0x00ff00ffu);
-            ohi += wgt * ((h >> 8) & 0x00ff00ffu);
-            left += wgt * lf[p];
-        }
-        const uint32_t a = 2u * elo + olo + ((olo << 16) | left);         // destination pixels 0 (low half) and 1
-        const uint32_t b = 2u * ehi + ohi + ((olo >> 16) | (ohi << 16));  // destination pixels 2 and 3
-        uint32_t v = ((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8) | (((b >> 4) & 0xffu) << 16) | (((b >> 20) & 0xffu) << 24);
-        if (x0 + 4 > dw) v &= x0 < dw ? 0xffffffffu >> (8 * (x0 + 4 - dw)) : 0u; // pitch padding is written as zero
-        out[r] = (y + r >= 0 && y + r < dh) ? v : 0u;
+        for (int p = 0; p < 5; ++p) lo[p] &= mlo, hi[p] &= mhi;
+        uint32_t v0 = gauss3_rows(lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], lf[0], lf[1], lf[2]);
+        uint32_t v1 = gauss3_rows(lo[2], lo[3], lo[4], hi[2], hi[3], hi[4], lf[2], lf[3], lf[4]);
+        const uint32_t mx = x0 + 4 > dw ? (x0 < dw ? 0xffffffffu >> (8 * (x0 + 4 - dw)) : 0u) : 0xffffffffu; // padding is written as zero
+        out0 = (y >= 0 && y < dh) ? (v0 & mx) : 0u;
+        out1 = (y + 1 >= 0 && y + 1 < dh) ? (v1 & mx) : 0u;
     }
-    out0 = out[0];
-    out1 = out[1];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -130,8 +142,9 @@ struct PyrArgs {
     int pitch[kPyrMaxProduced + 1];    // pitch[0] = source pitch
     int w[kPyrMaxProduced + 1], h[kPyrMaxProduced + 1];
     int n;                             // produced levels
-    int stride[kPyrMaxProduced + 1];   // LDS row stride of level k's region
-    int lds_off[kPyrMaxProduced + 1];  // LDS byte offset of level k's region (levels alternate between two areas)
+    int stride[kPyrMaxProduced + 1];   // LDS row stride of level k's region (multiple of 4)
+    int lds_off[kPyrMaxProduced + 1];  // LDS byte offset of level k's region (levels alternate between two areas; 16 B of slack in front)
+    int delta[kPyrMaxProduced + 1];    // LDS column of level k's pixel x is x - X_k + delta[k]; delta[k] = 2*delta[k+1], multiples of 4
     int dst0_pitch;                    // pitch of the optional level-0 copy dst[0]
     // Row window of the destination planes (sharded sessions): dst[k] holds global rows [row0[k], row1[k]) and only those
     // are stored; the source frame is always complete.  by0 = first tile row of the grid.  Whole levels: 0 / h[k] / 0.
@@ -167,37 +180,46 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
         }
     }
 
+    // LDS layout.  Level k (1 <= k < n) keeps the rows y in [Y_k - H_k, Y_k + T_k) at row y - Y_k + H_k and the pixel x at
+    // column x - X_k + delta[k] of its region.  With delta[k] = 2*delta[k+1] the source bytes of 4 destination pixels that
+    // start at a multiple of 4 are the bytes 8c-1 .. 8c+7 of the source rows: a thread writes its 4 pixels as ONE aligned
+    // dword and reads a 3x9-byte source patch as 9 aligned dwords (byte accesses cost an instruction each, and the pyramid's
+    // instructions come out of the LK stage's issue slots).  Columns left of the needed halo hold unneeded values.
+
     // ---- level 1 straight from HBM (the bulk of the work: no LDS staging of level 0) -----------------------------------------
     // a thread produces 4 horizontally adjacent pixels (global x a multiple of 4) of two rows from one set of loads
     {
         const int Hn = H0 >> 1, Tn = kPyrTile >> 1, Xn = X0 >> 1, Yn = Y0 >> 1;
+        const bool keep = A.n > 1; // level 1 is only kept in LDS when a level 2 is built from it
         uint8_t *dstr = lds + A.lds_off[1];
-        const int ds = A.stride[1];
+        const int ds = A.stride[1], dl = A.delta[1];
         const int rn = Tn + Hn;
         const int hq = (Hn + 3) & ~3, groups = (Tn + hq + 3) / 4;
         const int pairs = (rn + 1) / 2;
+        // interior tile: every level-0 byte the block reads exists -- left/top halo (columns from X0 - 2*hq - 4: the dword
+        // holding the leftmost tap; rows from Y0 - 2*Hn - 1) and the two rows a trailing odd row pair reads past the tile
+        const bool interior = X0 >= 2 * hq + 4 && Y0 >= 2 * Hn + 1 && X0 + kPyrTile <= A.w[0] && Y0 + kPyrTile + 2 <= A.h[0];
         for (int i = tid; i < groups * pairs; i += kPyrThreads) {
             const int ry = 2 * (i / groups), g = i % groups;
             const int y = Yn - Hn + ry, xb = Xn - hq + 4 * g; // global coordinates at level 1
             uint32_t pk[2] = {0u, 0u};
-            if (xb >= 0 && xb < A.w[1] && y + 1 >= 0 && y < A.h[1]) down4x2(A.src, A.pitch[0], A.h[0], A.w[0], A.w[1], A.h[1], xb, y, pk[0], pk[1]);
+            if (interior)
+                down4x2<true>(A.src, A.pitch[0], A.h[0], A.w[0], A.w[1], A.h[1], xb, y, pk[0], pk[1]);
+            else if (xb >= 0 && xb < A.w[1] && y + 1 >= 0 && y < A.h[1])
+                down4x2<false>(A.src, A.pitch[0], A.h[0], A.w[0], A.w[1], A.h[1], xb, y, pk[0], pk[1]);
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 if (ry + r >= rn) continue;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int rx = xb + q - (Xn - Hn);
-                    if (rx >= 0 && rx < rn) dstr[(ry + r) * ds + rx] = (uint8_t)(pk[r] >> (8 * q));
-                }
+                if (keep) *reinterpret_cast<uint32_t *>(dstr + (ry + r) * ds + (xb - Xn + dl)) = pk[r];
                 // the tile's own part (not the halo) goes to HBM
                 if (ry + r >= Hn && y + r >= A.row0[1] && y + r < A.row1[1] && xb >= Xn && xb < A.w[1]) {
                     uint8_t *row = A.dst[1] + (size_t)(y + r - A.row0[1]) * (size_t)A.pitch[1];
-                    if (xb + 3 < Xn + Tn && xb + 3 < A.w[1]) {
+                    if (xb + 3 < A.w[1]) {
                         *reinterpret_cast<uint32_t *>(row + xb) = pk[r];
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (xb + q < Xn + Tn && xb + q < A.w[1]) row[xb + q] = (uint8_t)(pk[r] >> (8 * q));
+                            if (xb + q < A.w[1]) row[xb + q] = (uint8_t)(pk[r] >> (8 * q));
                     }
                 }
             }
@@ -215,44 +237,44 @@ __device__ __forceinline__ void pyramid_block(const PyrArgs &A, int bx, int by, 
 
     // ---- deeper levels from LDS --------------------------------------------------------------------------------------
     for (int k = 1; k < A.n; ++k) {
-        // level k region origin O_k = X_k - H_k (size T_k + H_k); O_k = 2*O_{k+1} - 1, so the taps 2x-1..2x+1 of the
-        // level-(k+1) pixel at region column rx are the level-k region columns 2*rx .. 2*rx+2
+        // producing level k+1 from level k: the taps 2x-1..2x+1 / 2y-1..2y+1 of the pixel at region row ry are the source
+        // region rows 2*ry .. 2*ry+2 (H_k = 2*H_{k+1} + 1) and, for a group of 4 pixels starting at region column c, the
+        // source columns 2*(c - delta[k+1]) + delta[k] - 1 ... + 7 = (8-aligned) - 1 ... + 7
         const int Hn = H0 >> (k + 1), Tn = kPyrTile >> (k + 1), Xn = X0 >> (k + 1), Yn = Y0 >> (k + 1);
+        const bool keep = k + 1 < A.n;
         const uint8_t *srcr = lds + A.lds_off[k];
         uint8_t *dstr = lds + A.lds_off[k + 1];
-        const int ss = A.stride[k], ds = A.stride[k + 1];
+        const int ss = A.stride[k], ds = A.stride[k + 1], sl = A.delta[k], dl = A.delta[k + 1];
         const int rn = Tn + Hn;
-        // a thread produces 4 horizontally adjacent pixels whose global x is a multiple of 4 (dword store of the tile part)
-        const int hq = (Hn + 3) & ~3, groups = (Tn + hq + 3) / 4;
+        const int hq = (Hn + 3) & ~3, groups = (Tn + hq + 3) / 4; // the last group may reach past the tile (T < 4): unneeded pixels
         for (int i = tid; i < groups * rn; i += kPyrThreads) {
             const int ry = i / groups, g = i % groups;
             const int y = Yn - Hn + ry, xb = Xn - hq + 4 * g; // global coordinates at level k+1
-            uint32_t packed = 0;
+            const int sc = 2 * (4 * g - hq) + sl;             // source column of tap 2*xb (multiple of 4, >= 0)
+            const uint8_t *p0 = srcr + (2 * ry) * ss + sc, *p1 = p0 + ss, *p2 = p1 + ss;
+            uint32_t v = gauss3_rows(*reinterpret_cast<const uint32_t *>(p0), *reinterpret_cast<const uint32_t *>(p1),
+                                     *reinterpret_cast<const uint32_t *>(p2), *reinterpret_cast<const uint32_t *>(p0 + 4),
+                                     *reinterpret_cast<const uint32_t *>(p1 + 4), *reinterpret_cast<const uint32_t *>(p2 + 4),
+                                     *reinterpret_cast<const uint32_t *>(p0 - 4) >> 24, *reinterpret_cast<const uint32_t *>(p1 - 4) >> 24,
+                                     *reinterpret_cast<const uint32_t *>(p2 - 4) >> 24);
+            // pixels outside the image are zero (they are the skipped taps of the next level)
+            uint32_t m = 0u;
+            if (y >= 0 && y < A.h[k + 1]) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int x = xb + q, rx = x - (Xn - Hn);
-                int v = 0;
-                if (rx >= 0 && rx < rn) {
-                    if (x >= 0 && y >= 0 && x < A.w[k + 1] && y < A.h[k + 1]) {
-                        const uint8_t *p = srcr + (2 * ry) * ss + 2 * rx;
-                        const int c0 = p[0] + 2 * p[ss] + p[2 * ss];
-                        const int c1 = p[1] + 2 * p[ss + 1] + p[2 * ss + 1];
-                        const int c2 = p[2] + 2 * p[ss + 2] + p[2 * ss + 2];
-                        v = (c0 + 2 * c1 + c2) >> 4;
-                    }
-                    dstr[ry * ds + rx] = (uint8_t)v;
-                }
-                packed |= (uint32_t)v << (8 * q);
+                for (int q = 0; q < 4; ++q)
+                    if (xb + q >= 0 && xb + q < A.w[k + 1]) m |= 0xffu << (8 * q);
             }
+            v &= m;
+            if (keep) *reinterpret_cast<uint32_t *>(dstr + ry * ds + (xb - Xn + dl)) = v;
             // the tile's own part (not the halo) goes to HBM
             if (ry >= Hn && y >= A.row0[k + 1] && y < A.row1[k + 1] && xb >= Xn && xb < A.w[k + 1]) {
                 uint8_t *row = A.dst[k + 1] + (size_t)(y - A.row0[k + 1]) * (size_t)A.pitch[k + 1];
                 if (xb + 3 < Xn + Tn && xb + 3 < A.w[k + 1]) {
-                    *reinterpret_cast<uint32_t *>(row + xb) = packed;
+                    *reinterpret_cast<uint32_t *>(row + xb) = v;
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (xb + q < Xn + Tn && xb + q < A.w[k + 1]) row[xb + q] = (uint8_t)(packed >> (8 * q));
+                        if (xb + q < Xn + Tn && xb + q < A.w[k + 1]) row[xb + q] = (uint8_t)(v >> (8 * q));
                 }
             }
         }
