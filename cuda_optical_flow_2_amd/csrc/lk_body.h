@@ -36,6 +36,9 @@ struct LkTable {
 #ifndef OFX_LK_NT_STORES
 #define OFX_LK_NT_STORES 1
 #endif
+#ifndef OFX_LK_PROGRESS_PRIORITY
+#define OFX_LK_PROGRESS_PRIORITY 1
+#endif
 struct __attribute__((packed)) UnalignedU32 {
     uint32_t v;
 };
@@ -814,6 +817,22 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         }
     };
 
+    // The waves of a SIMD are served oldest first, not in turn: left alone, the four LK waves of a SIMD finish one after the
+    // other (70 / 95 / 125 / 165 us of a 186 us launch, tools/stream_timeline.py) and the last one runs its final quarter
+    // alone, at the ~60 % issue rate of a lone wave.  Each wave therefore lowers its own priority as it advances through its
+    // strip (3 -> 0 at the quarter marks): whoever is behind is served first, and the waves of a SIMD finish together.
+#if OFX_LK_PROGRESS_PRIORITY
+    const int q1 = nsteps / 4, q2 = nsteps / 2, q3 = nsteps - nsteps / 4;
+    __builtin_amdgcn_s_setprio(3);
+#define OFX_LK_PRIO_STEP()                               \
+    do {                                                 \
+        if (s >= q3) __builtin_amdgcn_s_setprio(0);      \
+        else if (s >= q2) __builtin_amdgcn_s_setprio(1); \
+        else if (s >= q1) __builtin_amdgcn_s_setprio(2); \
+    } while (0)
+#else
+#define OFX_LK_PRIO_STEP() ((void)0)
+#endif
     int s = 0;
     while (true) {
         body(std::integral_constant<int, 0>{}, s);
@@ -822,7 +841,9 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         if (++s >= nsteps) break;
         body(std::integral_constant<int, 2>{}, s);
         if (++s >= nsteps) break;
+        OFX_LK_PRIO_STEP();
     }
+#undef OFX_LK_PRIO_STEP
 }
 
 

@@ -58,7 +58,13 @@ struct StreamArgs {
     int first[kPyrStages + 1];
     int blocks_x[kPyrStages];
     int n_corner;
+    unsigned long long *trace; // optional (ofx_debug_stream_trace): per block, start and end time (100 MHz wall clock)
+    int trace_blocks;
 };
+
+unsigned long long *g_stream_trace = nullptr; // tools/stream_timeline.py
+int g_stream_trace_blocks = 0;
+int g_trace_header[kPyrStages + 1] = {0};
 
 // lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu would spill there
 #ifndef OFX_STREAM_MIN_BLOCKS
@@ -69,11 +75,15 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const unsigned long long t_start = S.trace ? wall_clock64() : 0ull;
     // readfirstlane: the wave index is uniform, and everything derived from it (strip rows, row pointers, loop counters)
     // must live in SGPRs as it does in the stand-alone kernel
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (b < OFX_STREAM_MAX_BATCH) {
         // one corner chain per block (wave 0), so that the chains land on different CUs
+        // the short latency-bound stages go first whenever they are ready to issue (the LK waves lower their own priority
+        // from 3 to 0 as they advance, lk_body.h)
+        __builtin_amdgcn_s_setprio(3);
         if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
     } else if (b < S.first[0]) {
         lk_wave<R, MODE, false, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
@@ -81,7 +91,12 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
         const int pb = b - S.first[i];
+        __builtin_amdgcn_s_setprio(3);
         pyramid_block(S.pyr[i], pb % S.blocks_x[i], pb / S.blocks_x[i] + S.pyr[i].by0, tid, lds);
+    }
+    if (S.trace && b < S.trace_blocks && (tid & 63) == 0) { // one record per wave: 4 per block
+        S.trace[2 * (4 * b + wv)] = t_start;
+        S.trace[2 * (4 * b + wv) + 1] = wall_clock64();
     }
 }
 
@@ -98,7 +113,7 @@ int env_int(const char *name, int dflt)
 }
 
 // One strip height for all levels (so all waves run about equally long): the smallest that keeps the wave count within
-// ~95% of `capacity` (waves resident at once), but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
+// `capacity` (lk_wave_target), but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
 // The grid is sized to fit in ONE residency round: every wave runs for the whole kernel, so a second, partly filled
 // round would nearly double the run time.
 template <int R>
@@ -112,7 +127,7 @@ int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
     for (; strip_h < max_rows; ++strip_h) {
         long waves = 0;
         for (int i = 0; i < n; ++i) waves += (long)ofx_div_up(lv[i].a.w, G::OUT_W) * ofx_div_up(lv[i].rows_out, strip_h);
-        if (waves * 100 <= (long)capacity * 95) break;
+        if (waves <= (long)capacity) break;
     }
     LkTable t{};
     t.n = n;
@@ -146,7 +161,10 @@ int lk_wave_target(K kernel, int threads, size_t lds, int reserve, int dflt_per_
     int per_simd = env_int("OFX_LK_WAVES_PER_SIMD", dflt_per_simd);
     if (per_simd > occ - reserve) per_simd = occ - reserve;
     if (per_simd < 1) per_simd = 1;
-    return env_int("OFX_LK_TARGET_WAVES", cus * 4 * per_simd);
+    // with wave slots to spare the plan may use the whole target (an uneven placement still fits in one round); a plan
+    // that needs every slot keeps 5 % back, because a second, mostly empty round would double the run time
+    const int fill = env_int("OFX_LK_FILL", per_simd < occ ? 100 : 95);
+    return env_int("OFX_LK_TARGET_WAVES", (int)((long)cus * 4 * per_simd * fill / 100));
 }
 
 template <int R, int MODE, bool SUMS>
@@ -175,6 +193,10 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
     S.first[0] = OFX_STREAM_MAX_BATCH + lk_blocks;
     for (int i = 0; i < kPyrStages; ++i) S.first[i + 1] = S.first[i] + stage_blocks[i];
     const int blocks = S.first[kPyrStages];
+    S.trace = g_stream_trace;
+    S.trace_blocks = g_stream_trace_blocks;
+    if (g_stream_trace) // header: block ranges of this launch
+        for (int i = 0; i <= kPyrStages; ++i) g_trace_header[i] = S.first[i];
     size_t corner_lds = 0; // a corner wave's scratch: the chain's floats and the cached corners of its levels
     for (int i = 0; i < S.n_corner; ++i) {
         const size_t need = (size_t)kCornerScratch + kCornerTileBytes + (size_t)S.corner[i].levels * kCornerCacheBytes;
@@ -339,6 +361,18 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     hipStream_t st = ofx_stream(stream);
     return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, stage_blocks, lds, st)
                                      : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, stage_blocks, lds, st);
+}
+
+// Debug / measurement hook (tools/stream_timeline.py): with a device buffer of 8 * capacity_blocks uint64 set, every
+// wave of every later ofx_stream_launch records its start and end time there; first[] (size 9) receives the block ranges of
+// the last launch.  d_buf = NULL switches it off.
+extern "C" int ofx_debug_stream_trace(unsigned long long *d_buf, int capacity_blocks, int *first)
+{
+    g_stream_trace = d_buf;
+    g_stream_trace_blocks = d_buf ? capacity_blocks : 0;
+    if (first)
+        for (int i = 0; i <= kPyrStages; ++i) first[i] = g_trace_header[i];
+    return OFX_OK;
 }
 
 extern "C" int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream)

@@ -152,6 +152,11 @@ typedef struct ofx_stream_stages {
     int n_lk;
 } ofx_stream_stages;
 int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
+/* Measurement hook: with a device buffer of 8 * capacity_blocks uint64 set, every wave of every later ofx_stream_launch
+ * records its start and end time (100 MHz wall clock) at [2 * (4 * block + wave)]; first (9 ints, may be NULL) receives
+ * the block ranges of the last launch (corner blocks first, then LK up to first[0], then the pyramid stages).
+ * d_buf = NULL switches it off.  Process-global, not thread-safe. */
+int ofx_debug_stream_trace(unsigned long long *d_buf, int capacity_blocks, int *first);
 
 /* Same level, but stopping before the solve: writes the five window sums
  * (Sxx, Syy, Sxy, Sxt, Syt) as int32 planes of w ints per row.  Test/inspection
