@@ -24,6 +24,7 @@
 
 #include "corner_body.h"
 #include "lk_body.h"
+#include "pyr_march.h"
 #include "stages_body.h"
 
 using namespace ofx_dev;
@@ -49,14 +50,13 @@ constexpr int kPyrStages = 2 * OFX_STREAM_MAX_BATCH; // per frame of the tick: i
 constexpr int kCornerScratch = 128;                  // LDS of a corner block: the chain's floats, then the cached corners
 struct StreamArgs {
     LkTable lk;
-    PyrArgs pyr[kPyrStages];
+    PyrMarchArgs pyr[kPyrStages];
     CornerArgs corner[OFX_STREAM_MAX_BATCH];
     // blocks [0, OFX_STREAM_MAX_BATCH) = one corner wave each; [.., first[0]) LK (four waves per block);
-    // [first[i], first[i+1]) pyramid stage i.
+    // [first[i], first[i+1]) pyramid stage i (four marching waves per block, pyr_march.h).
     // The LK blocks come first and are planned for a whole number of waves per SIMD (lk_wave_target): they all start at
     // once and run for the whole launch, while the short staging blocks stream through the remaining slots underneath.
     int first[kPyrStages + 1];
-    int blocks_x[kPyrStages];
     int n_corner;
     unsigned long long *trace; // optional (ofx_debug_stream_trace): per block, start and end time (100 MHz wall clock)
     int trace_blocks;
@@ -90,9 +90,8 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
-        const int pb = b - S.first[i];
         __builtin_amdgcn_s_setprio(3);
-        pyramid_block(S.pyr[i], pb % S.blocks_x[i], pb / S.blocks_x[i] + S.pyr[i].by0, tid, lds);
+        pyr_march_wave(S.pyr[i], 4 * (b - S.first[i]) + wv, tid & 63);
     }
     if (S.trace && b < S.trace_blocks && (tid & 63) == 0) { // one record per wave: 4 per block
         S.trace[2 * (4 * b + wv)] = t_start;
@@ -326,25 +325,19 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     size_t lds = 0;
     int stage_blocks[kPyrStages] = {0};
     int any = 0;
-    for (int i = 0; i < kPyrStages; ++i) S.blocks_x[i] = 1;
     for (int i = 0; i < g->n_pyr; ++i) {
         const ofx_pyramid_stage &P = g->pyr[i];
         if (P.levels < 2) continue;
-        int bx = 0, by = 0;
-        size_t need = 0;
-        OFX_TRY(ofx_pyramid_args(P.d_frame, P.frame_pitch, P.w, P.h, P.d_levels, P.pitches, P.levels, P.d_levels[0], P.pitches[0],
-                                 P.windowed ? P.row0 : nullptr, P.windowed ? P.rows : nullptr, &S.pyr[2 * i], &need, &bx, &by));
-        S.blocks_x[2 * i] = bx;
-        stage_blocks[2 * i] = bx * by;
-        lds = need > lds ? need : lds;
+        int items = 0;
+        OFX_TRY(ofx_pyramid_march_args(P.d_frame, P.frame_pitch, P.w, P.h, P.d_levels, P.pitches, P.levels, P.d_levels[0], P.pitches[0],
+                                       P.windowed ? P.row0 : nullptr, P.windowed ? P.rows : nullptr, &S.pyr[2 * i], &items));
+        stage_blocks[2 * i] = ofx_div_up(items, 4);
         if (P.patch_levels >= 2) {
             OFX_REQUIRE(P.patch_w > 0 && P.patch_h > 0 && P.patch_w <= P.w && P.patch_h <= P.h,
                         "ofx_stream_launch: the patch must lie inside the frame");
-            OFX_TRY(ofx_pyramid_args(P.d_frame, P.frame_pitch, P.patch_w, P.patch_h, P.d_patch_levels, P.patch_pitches, P.patch_levels,
-                                     P.d_patch_levels[0], P.patch_pitches[0], nullptr, nullptr, &S.pyr[2 * i + 1], &need, &bx, &by));
-            S.blocks_x[2 * i + 1] = bx;
-            stage_blocks[2 * i + 1] = bx * by;
-            lds = need > lds ? need : lds;
+            OFX_TRY(ofx_pyramid_march_args(P.d_frame, P.frame_pitch, P.patch_w, P.patch_h, P.d_patch_levels, P.patch_pitches, P.patch_levels,
+                                           P.d_patch_levels[0], P.patch_pitches[0], nullptr, nullptr, &S.pyr[2 * i + 1], &items));
+            stage_blocks[2 * i + 1] = ofx_div_up(items, 4);
         }
         any += stage_blocks[2 * i] + stage_blocks[2 * i + 1];
     }

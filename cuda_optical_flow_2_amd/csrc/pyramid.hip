@@ -1,6 +1,7 @@
 // Pyramid downsample, global shift, flow composition and layout helpers for gfx950.
 // All of these are pure streaming kernels (HBM-bound); they use 4-pixels-per-lane dword accesses where the layout
 // allows it and one wave-row mapping so that every load/store instruction touches one contiguous span.
+#include "pyr_march.h"
 #include "stages_body.h"
 
 using namespace ofx_dev;
@@ -220,6 +221,65 @@ int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t 
     *blocks_x = ofx_div_up(w, kPyrTile);
     *blocks_y = t1 - t0;
     *out = a;
+    return OFX_OK;
+}
+
+// Arguments of the marching pyramid (pyr_march.h, the stream kernel's pyramid stage); *items = waves it needs.
+int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
+                           uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, PyrMarchArgs *out, int *items)
+{
+    OFX_REQUIRE(d_level0 && d_levels && pitches && w > 0 && h > 0, "ofx_stream_launch: bad pyramid arguments");
+    OFX_REQUIRE(levels >= 2 && levels - 1 <= kMarchMaxProduced, "ofx_stream_launch: %d levels unsupported (2..%d)", levels, kMarchMaxProduced + 1);
+    OFX_REQUIRE(((uintptr_t)d_level0 & 3) == 0 && (pitch0 & 3) == 0 && pitch0 >= 8 && pitch0 >= w,
+                "ofx_stream_launch: level 0 must be 4-byte aligned with a pitch that is a multiple of 4, >= 8 and >= the width");
+    PyrMarchArgs a{};
+    a.src = d_level0;
+    a.src_pitch = pitch0;
+    a.n = levels - 1;
+    a.dst[0] = d_level0_copy;
+    a.pitch[0] = copy_pitch;
+    a.w[0] = w;
+    a.h[0] = h;
+    for (int k = 1; k < levels; ++k) {
+        OFX_REQUIRE(((w >> (k - 1)) & 1) == 0 && ((h >> (k - 1)) & 1) == 0, "ofx_stream_launch: level %d has odd dimensions", k - 1);
+        OFX_REQUIRE(d_levels[k] != nullptr && pitches[k] >= (w >> k) && (pitches[k] & 3) == 0, "ofx_stream_launch: bad plane for level %d", k);
+        a.dst[k] = d_levels[k];
+        a.pitch[k] = pitches[k];
+        a.w[k] = w >> k;
+        a.h[k] = h >> k;
+    }
+    OFX_REQUIRE(d_level0_copy == nullptr || (copy_pitch >= w && (copy_pitch & 3) == 0), "ofx_stream_launch: bad level-0 copy pitch");
+    const int step = 1 << a.n;
+    int lo = h, hi = 0;
+    for (int k = 0; k < levels; ++k) {
+        a.row0[k] = row0 ? row0[k] : 0;
+        a.row1[k] = row0 ? row0[k] + rows[k] : (h >> k);
+        OFX_REQUIRE(a.row0[k] >= 0 && a.row0[k] <= a.row1[k] && a.row1[k] <= (h >> k), "ofx_stream_launch: bad row window at level %d", k);
+        if (a.row1[k] <= a.row0[k] || (k == 0 && d_level0_copy == nullptr)) continue;
+        lo = (a.row0[k] << k) < lo ? (a.row0[k] << k) : lo;
+        hi = (a.row1[k] << k) > hi ? (a.row1[k] << k) : hi;
+    }
+    if (hi <= lo) {
+        *out = a;
+        *items = 0;
+        return OFX_OK;
+    }
+    a.y_lo = lo / step * step;
+    a.y_hi = hi < h ? hi : h;
+    // lanes of overlap on the left: 8*halo >= 2^n - 1, and the tile width a multiple of 2^n (pixels of the deepest level
+    // sit in every 2^(n-3)-th lane)
+    a.halo = a.n <= 3 ? 1 : 1 << (a.n - 3);
+    a.tile_w = (64 - a.halo) * 8;
+    a.tiles_x = ofx_div_up(w, a.tile_w);
+    // strips: ~16 per frame keep a wave's march long against its 2^n priming rows and the wave count modest; at most 128 rows
+    const int span = a.y_hi - a.y_lo;
+    int sh = ofx_div_up(ofx_div_up(span, 16), step) * step;
+    sh = sh > 128 ? 128 / step * step : sh;
+    sh = sh < step ? step : sh;
+    a.strip_h = sh;
+    a.strips = ofx_div_up(span, sh);
+    *out = a;
+    *items = a.tiles_x * a.strips;
     return OFX_OK;
 }
 
