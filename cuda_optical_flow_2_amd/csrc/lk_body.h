@@ -73,6 +73,21 @@ __device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b)
 #endif
 }
 __device__ __forceinline__ void gstore_i32(int32_t *p, int32_t v) { *(OFX_GLOBAL int32_t *)p = v; }
+// stores at (wave-uniform base) + (per-lane byte offset)
+__device__ __forceinline__ void gstore_u32(uint8_t *base, uint32_t off, uint32_t v)
+{
+    *(OFX_GLOBAL uint32_t *)((OFX_GLOBAL uint8_t *)base + lane_off(off)) = v;
+}
+__device__ __forceinline__ void gstore_u32x2(uint8_t *base, uint32_t off, uint32_t a, uint32_t b)
+{
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+    *(OFX_GLOBAL u32x2 *)((OFX_GLOBAL uint8_t *)base + lane_off(off)) = u32x2{a, b};
+}
+__device__ __forceinline__ void gstore_u16(uint8_t *base, uint32_t off, uint16_t v)
+{
+    *(OFX_GLOBAL uint16_t *)((OFX_GLOBAL uint8_t *)base + lane_off(off)) = v;
+}
+__device__ __forceinline__ void gstore_u8(uint8_t *base, uint32_t off, uint8_t v) { *((OFX_GLOBAL uint8_t *)base + lane_off(off)) = v; }
 
 // a wave-uniform value, made opaque in an SGPR (no instruction is emitted)
 template <typename T>

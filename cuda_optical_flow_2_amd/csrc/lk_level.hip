@@ -94,8 +94,12 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         pyr_march_wave(S.pyr[i], 4 * (b - S.first[i]) + wv, tid & 63);
     }
     if (S.trace && b < S.trace_blocks && (tid & 63) == 0) { // one record per wave: 4 per block
+        // where the wave ran: HW_ID (wave / SIMD / CU / SH / SE) in bits 32.., XCC_ID in bits 48.. of the start word's top
+        const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (15 << 11));  // HW_REG_HW_ID, bits 0..15
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)); // HW_REG_XCC_ID, bits 0..3
         S.trace[2 * (4 * b + wv)] = t_start;
-        S.trace[2 * (4 * b + wv) + 1] = wall_clock64();
+        S.trace[2 * (4 * b + wv) + 1] = (wall_clock64() & 0x0000ffffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 48);
+        S.trace[2 * (4 * b + wv)] = (t_start & 0x0000ffffffffffffull) | ((unsigned long long)(xcc & 0xfu) << 48);
     }
 }
 
@@ -325,18 +329,26 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     size_t lds = 0;
     int stage_blocks[kPyrStages] = {0};
     int any = 0;
+    // marching-pyramid waves wanted per frame: all the frames of the tick together ~0.85 per SIMD (see ofx_pyramid_march_args)
+    static const int simds = [] {
+        int dev = 0, cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        return 4 * cus;
+    }();
+    const int pyr_target = g->n_pyr > 0 ? env_int("OFX_PYR_WAVES", simds * 85 / 100) / g->n_pyr : 0;
     for (int i = 0; i < g->n_pyr; ++i) {
         const ofx_pyramid_stage &P = g->pyr[i];
         if (P.levels < 2) continue;
         int items = 0;
         OFX_TRY(ofx_pyramid_march_args(P.d_frame, P.frame_pitch, P.w, P.h, P.d_levels, P.pitches, P.levels, P.d_levels[0], P.pitches[0],
-                                       P.windowed ? P.row0 : nullptr, P.windowed ? P.rows : nullptr, &S.pyr[2 * i], &items));
+                                       P.windowed ? P.row0 : nullptr, P.windowed ? P.rows : nullptr, pyr_target, &S.pyr[2 * i], &items));
         stage_blocks[2 * i] = ofx_div_up(items, 4);
         if (P.patch_levels >= 2) {
             OFX_REQUIRE(P.patch_w > 0 && P.patch_h > 0 && P.patch_w <= P.w && P.patch_h <= P.h,
                         "ofx_stream_launch: the patch must lie inside the frame");
             OFX_TRY(ofx_pyramid_march_args(P.d_frame, P.frame_pitch, P.patch_w, P.patch_h, P.d_patch_levels, P.patch_pitches, P.patch_levels,
-                                           P.d_patch_levels[0], P.patch_pitches[0], nullptr, nullptr, &S.pyr[2 * i + 1], &items));
+                                           P.d_patch_levels[0], P.patch_pitches[0], nullptr, nullptr, 16, &S.pyr[2 * i + 1], &items));
             stage_blocks[2 * i + 1] = ofx_div_up(items, 4);
         }
         any += stage_blocks[2 * i] + stage_blocks[2 * i + 1];

@@ -57,7 +57,8 @@ int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t 
                      size_t *lds_bytes, int *blocks_x, int *blocks_y);
 // the stream kernel's pyramid stage (pyr_march.h); *items = waves needed
 int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
-                           uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, ofx_dev::PyrMarchArgs *out, int *items);
+                           uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, int target_waves,
+                           ofx_dev::PyrMarchArgs *out, int *items);
 int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *out, int *blocks_out);
 // cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerArgs::status
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,

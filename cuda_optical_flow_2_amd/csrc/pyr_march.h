@@ -89,8 +89,9 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
         lo = hi = 0u;
         if (r >= 0 && r < A.h[0]) { // uniform
             const uint8_t *row = A.src + (size_t)r * (size_t)A.src_pitch;
-            lo = *reinterpret_cast<const uint32_t *>(row + lo_off);
-            hi = *reinterpret_cast<const uint32_t *>(row + hi_off);
+            pin_scalar(row); // scalar row base + 32-bit lane offset: no 64-bit VALU address arithmetic
+            lo = gload_u32(row, lo_off);
+            hi = gload_u32(row, hi_off);
         }
     };
     auto load_row = [&](int r, uint32_t &lo, uint32_t &hi) {
@@ -103,10 +104,30 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
         return y0 >= Ys && y0 < Ye && yk >= A.row0[k] && yk < A.row1[k];
     };
 
-    const uint32_t M = 0x00ff00ffu;
     uint32_t c_lo = 0u, c_hi = 0u;           // level-0 row 2*y1 - 1
     if (r_start > 0) load_row(r_start - 1, c_lo, c_hi);
-    uint32_t carry[kMarchMaxProduced + 1] = {0, 0, 0, 0, 0, 0, 0}, mid[kMarchMaxProduced + 1] = {0, 0, 0, 0, 0, 0, 0};
+    const uint32_t M = 0x00ff00ffu;
+    // per level k >= 2: the source rows 2y-1 (carry) and 2y (mid) of the output row in the making.  Scalars, not arrays:
+    // hipcc copied whole arrays around every conditional update (~70 v_mov per step).
+    uint32_t carry2 = 0, carry3 = 0, carry4 = 0, carry5 = 0, carry6 = 0, mid2 = 0, mid3 = 0, mid4 = 0, mid5 = 0, mid6 = 0;
+    auto level2 = [&](uint32_t c, uint32_t m, uint32_t o) { // source: 4 pixels per lane -> 2 pixels
+        const uint32_t E = (c & M) + 2u * (m & M) + (o & M), O = ((c >> 8) & M) + 2u * ((m >> 8) & M) + ((o >> 8) & M);
+        const uint32_t left = (uint32_t)lane_shift_right((int)O) >> 16;
+        const uint32_t a = 2u * E + O + ((O << 16) | left);
+        return (((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8)) & m2;
+    };
+    auto level3 = [&](uint32_t c, uint32_t m, uint32_t o) { // 2 pixels per lane -> 1
+        const uint32_t E = (c & 0xffu) + 2u * (m & 0xffu) + (o & 0xffu), O = ((c >> 8) & 0xffu) + 2u * ((m >> 8) & 0xffu) + ((o >> 8) & 0xffu);
+        const uint32_t left = (uint32_t)lane_shift_right((int)O);
+        return ((left + 2u * E + O) >> 4) & m3;
+    };
+    auto level_n = [&](int k, uint32_t c, uint32_t m, uint32_t o) { // one pixel per 2^(k-4)-th lane -> one per 2^(k-3)-th
+        const int sft = 1 << (k - 4);
+        const uint32_t V = c + 2u * m + o; // zero in the lanes that hold no pixel
+        const uint32_t left = k == 4 ? (uint32_t)lane_shift_right((int)V) : march_shift_up(V, sft, lane);
+        const uint32_t right = k == 4 ? (uint32_t)lane_shift_left((int)V) : march_shift_down(V, sft, lane);
+        return ((left + 2u * V + right) >> 4) & mk[k];
+    };
 
     uint32_t e_lo, e_hi, o_lo, o_hi; // rows 2*y1, 2*y1 + 1 of the current step
     const int y1_begin = r_start >> 1, y1_end = (Ye + 1) >> 1;
@@ -121,9 +142,8 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
         // ---- arithmetic of the step: nothing is stored yet (gfx9 counts loads and stores in one counter and only orders
         // returns within a type, so a wait for the fetched rows with this step's stores outstanding would wait for those too)
         // level 1, row y1: vertical [1 2 1] of rows 2y1-1, 2y1, 2y1+1 on the even / odd bytes, then horizontal
-        uint32_t outv[kMarchMaxProduced + 1] = {0, 0, 0, 0, 0, 0, 0}; // outv[k]: the level-k row this step completed
-        int outy[kMarchMaxProduced + 1] = {0, 0, 0, 0, 0, 0, 0};
-        int n_out = 1;                                                // levels 1 .. n_out completed a row in this step
+        uint32_t out1, out2 = 0, out3 = 0, out4 = 0, out5 = 0, out6 = 0; // outK: the level-K row this step completed (K <= n_out)
+        int n_out = 1;
         uint32_t v;
         {
             const uint32_t elo = (c_lo & M) + 2u * (e_lo & M) + (o_lo & M), olo = ((c_lo >> 8) & M) + 2u * ((e_lo >> 8) & M) + ((o_lo >> 8) & M);
@@ -135,48 +155,57 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
             c_lo = o_lo;
             c_hi = o_hi;
         }
-        outv[1] = v;
-        outy[1] = y1;
-        // deeper levels: row idx of level k-1 just arrived as `v`
-        // (written without early exits: hipcc merged the per-level "mid[k] = v; break" tails into one store with a dynamic
-        // index, which put the array into scratch memory)
-        int idx = y1;
-        bool active = true; // uniform: level k-1 completed a row in this step
-#pragma unroll
-        for (int k = 2; k <= kMarchMaxProduced; ++k) {
-            active = active && k <= n;
-            const bool odd = (idx & 1) != 0;
-            mid[k] = (active && !odd) ? v : mid[k]; // an even source row only waits
-            active = active && odd;
-            if (!active) continue;
-            const uint32_t c = carry[k], m = mid[k], o = v;
-            carry[k] = o;
-            uint32_t out;
-            if (k == 2) { // source: 4 pixels per lane -> 2 pixels
-                const uint32_t E = (c & M) + 2u * (m & M) + (o & M), O = ((c >> 8) & M) + 2u * ((m >> 8) & M) + ((o >> 8) & M);
-                const uint32_t left = (uint32_t)lane_shift_right((int)O) >> 16;
-                const uint32_t a = 2u * E + O + ((O << 16) | left);
-                out = (((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8)) & m2;
-            } else if (k == 3) { // 2 pixels per lane -> 1
-                const uint32_t E = (c & 0xffu) + 2u * (m & 0xffu) + (o & 0xffu), O = ((c >> 8) & 0xffu) + 2u * ((m >> 8) & 0xffu) + ((o >> 8) & 0xffu);
-                const uint32_t left = (uint32_t)lane_shift_right((int)O);
-                out = ((left + 2u * E + O) >> 4) & m3;
-            } else { // one pixel per 2^(k-4)-th lane -> one per 2^(k-3)-th
-                const int s = 1 << (k - 4);
-                const uint32_t V = c + 2u * m + o; // zero in the lanes that hold no pixel
-                const uint32_t left = k == 4 ? (uint32_t)lane_shift_right((int)V) : march_shift_up(V, s, lane);
-                const uint32_t right = k == 4 ? (uint32_t)lane_shift_left((int)V) : march_shift_down(V, s, lane);
-                out = ((left + 2u * V + right) >> 4) & mk[k];
+        out1 = v;
+        // deeper levels: level k gets a source row every 2^(k-2) steps, an even one waits in mid, an odd one completes a row
+        if (n >= 2) {
+            if ((y1 & 1) == 0) {
+                mid2 = out1;
+            } else {
+                out2 = level2(carry2, mid2, out1);
+                carry2 = out1;
+                n_out = 2;
+                if (n >= 3) {
+                    if (((y1 >> 1) & 1) == 0) {
+                        mid3 = out2;
+                    } else {
+                        out3 = level3(carry3, mid3, out2);
+                        carry3 = out2;
+                        n_out = 3;
+                        if (n >= 4) {
+                            if (((y1 >> 2) & 1) == 0) {
+                                mid4 = out3;
+                            } else {
+                                out4 = level_n(4, carry4, mid4, out3);
+                                carry4 = out3;
+                                n_out = 4;
+                                if (n >= 5) {
+                                    if (((y1 >> 3) & 1) == 0) {
+                                        mid5 = out4;
+                                    } else {
+                                        out5 = level_n(5, carry5, mid5, out4);
+                                        carry5 = out4;
+                                        n_out = 5;
+                                        if (n >= 6) {
+                                            if (((y1 >> 4) & 1) == 0) {
+                                                mid6 = out5;
+                                            } else {
+                                                out6 = level_n(6, carry6, mid6, out5);
+                                                carry6 = out5;
+                                                n_out = 6;
+                                            }
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
             }
-            idx >>= 1;
-            v = out;
-            outv[k] = out;
-            outy[k] = idx;
-            n_out = k;
         }
 
         // ---- take the fetched rows (one wait: only loads are outstanding), then store
         asm volatile("" : "+v"(ne_lo), "+v"(ne_hi), "+v"(no_lo), "+v"(no_hi)); // the fetched rows are taken here, not earlier
+        // (scalar row pointer + 32-bit lane offset for every store, as in the LK march)
         if (own) {
             if (A.dst[0] != nullptr && col0 < A.w[0]) { // level-0 copy of the two rows
 #pragma unroll
@@ -186,30 +215,38 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
                         // 8 contiguous bytes per lane, 512 per wave; bytes beyond w are zero (masked loads) and land in the pitch
                         // padding.  (Streaming stores measured slower here: the step's single wait also covers the previous
                         // step's stores, and those take longer to complete when they bypass the L2.)
-                        uint8_t *d = A.dst[0] + (size_t)(r - A.row0[0]) * (size_t)A.pitch[0] + col0;
-                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+                        uint8_t *row = A.dst[0] + (size_t)(r - A.row0[0]) * (size_t)A.pitch[0];
+                        pin_scalar(row);
                         if (col0 + 8 <= A.pitch[0])
-                            *reinterpret_cast<u32x2 *>(d) = u32x2{t ? o_lo : e_lo, t ? o_hi : e_hi};
+                            gstore_u32x2(row, (uint32_t)col0, t ? o_lo : e_lo, t ? o_hi : e_hi);
                         else
-                            *reinterpret_cast<uint32_t *>(d) = t ? o_lo : e_lo;
+                            gstore_u32(row, (uint32_t)col0, t ? o_lo : e_lo);
                     }
                 }
             }
-            if (x1 < A.w[1] && emit_ok(1, y1))
-                *reinterpret_cast<uint32_t *>(A.dst[1] + (size_t)(y1 - A.row0[1]) * (size_t)A.pitch[1] + x1) = outv[1];
-#pragma unroll
-            for (int k = 2; k <= kMarchMaxProduced; ++k) {
-                if (k > n_out) break;
-                if (!emit_ok(k, outy[k])) continue;
-                uint8_t *d = A.dst[k] + (size_t)(outy[k] - A.row0[k]) * (size_t)A.pitch[k];
-                if (k == 2) {
-                    if (x2 < A.w[2]) *reinterpret_cast<uint16_t *>(d + x2) = (uint16_t)outv[2];
-                } else if (k == 3) {
-                    if (m3) d[x3] = (uint8_t)outv[3];
-                } else {
-                    if (mk[k]) d[xk[k]] = (uint8_t)outv[k];
-                }
+            if (x1 < A.w[1] && emit_ok(1, y1)) {
+                uint8_t *row = A.dst[1] + (size_t)(y1 - A.row0[1]) * (size_t)A.pitch[1];
+                pin_scalar(row);
+                gstore_u32(row, (uint32_t)x1, out1);
             }
+            auto store_level = [&](int k, uint32_t value) { // k >= 2, constant at every call site
+                const int yk = y1 >> (k - 1);
+                if (k > n_out || !emit_ok(k, yk)) return;
+                uint8_t *row = A.dst[k] + (size_t)(yk - A.row0[k]) * (size_t)A.pitch[k];
+                pin_scalar(row);
+                if (k == 2) {
+                    if (x2 < A.w[2]) gstore_u16(row, (uint32_t)x2, (uint16_t)value);
+                } else if (k == 3) {
+                    if (m3) gstore_u8(row, (uint32_t)x3, (uint8_t)value);
+                } else {
+                    if (mk[k]) gstore_u8(row, (uint32_t)xk[k], (uint8_t)value);
+                }
+            };
+            store_level(2, out2);
+            store_level(3, out3);
+            store_level(4, out4);
+            store_level(5, out5);
+            store_level(6, out6);
         }
         e_lo = ne_lo & m0lo;
         e_hi = ne_hi & m0hi;

@@ -226,7 +226,8 @@ int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t 
 
 // Arguments of the marching pyramid (pyr_march.h, the stream kernel's pyramid stage); *items = waves it needs.
 int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
-                           uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, PyrMarchArgs *out, int *items)
+                           uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, int target_waves, PyrMarchArgs *out,
+                           int *items)
 {
     OFX_REQUIRE(d_level0 && d_levels && pitches && w > 0 && h > 0, "ofx_stream_launch: bad pyramid arguments");
     OFX_REQUIRE(levels >= 2 && levels - 1 <= kMarchMaxProduced, "ofx_stream_launch: %d levels unsupported (2..%d)", levels, kMarchMaxProduced + 1);
@@ -271,11 +272,15 @@ int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, ui
     a.halo = a.n <= 3 ? 1 : 1 << (a.n - 3);
     a.tile_w = (64 - a.halo) * 8;
     a.tiles_x = ofx_div_up(w, a.tile_w);
-    // strips: ~16 per frame keep a wave's march long against its 2^n priming rows and the wave count modest; at most 128 rows
+    // Strips.  A marching wave runs at top priority next to the LK waves of its SIMD and takes its instructions out of their
+    // issue slots, so the waves should spread over the machine rather than pile work on a few SIMDs: the caller names the
+    // number of waves it wants (about 0.85 per SIMD for all the pyramids of a tick); each strip pays 2^n priming rows, so
+    // a strip is at least twice that and at most 128 rows.
     const int span = a.y_hi - a.y_lo;
-    int sh = ofx_div_up(ofx_div_up(span, 16), step) * step;
+    const int want = target_waves > 0 ? target_waves : 16 * a.tiles_x;
+    int sh = ofx_div_up(ofx_div_up(span * a.tiles_x, want), step) * step;
+    sh = sh < 2 * step ? 2 * step : sh;
     sh = sh > 128 ? 128 / step * step : sh;
-    sh = sh < step ? step : sh;
     a.strip_h = sh;
     a.strips = ofx_div_up(span, sh);
     *out = a;

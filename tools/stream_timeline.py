@@ -24,9 +24,12 @@ torch.cuda.synchronize()
 first = (C.c_int * 9)()
 Lib.ofx_debug_stream_trace(None, 0, first)
 first = list(first)
-t = buf.cpu().numpy().reshape(-1, 2).astype(np.float64)
+raw = buf.cpu().numpy().reshape(-1, 2)
 nb = first[-1]
-t = t[: 4 * nb]
+raw = raw[: 4 * nb]
+xcc = (raw[:, 0] >> 48) & 0xf
+hw = (raw[:, 1] >> 48) & 0xffff
+t = (raw & 0x0000ffffffffffff).astype(np.float64)
 ok = t[:, 1] > 0
 t0 = t[ok, 0].min()
 us = (t - t0) / 100.0  # 100 MHz
@@ -48,3 +51,20 @@ print(f"corner waves: {[(round(a,1), round(b,1)) for a, b in c if b > a]}")
 print(f"kernel span {us[ok,1].max():.1f} us")
 hist, edges = np.histogram(lk[:, 1], bins=12)
 print("LK end-time histogram:", [(round(e, 0), int(n)) for e, n in zip(edges[:-1], hist)])
+
+# where did the LK waves run?  HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
+sl = slice(4 * 4, 4 * first[0])
+m = ok[sl]
+simd = (hw[sl] >> 4) & 3; cu = (hw[sl] >> 8) & 0xf; sh = (hw[sl] >> 12) & 1; se = (hw[sl] >> 13) & 7
+key = (xcc[sl] * 8 + se) * 2 + sh
+key = (key * 16 + cu) * 4 + simd
+import collections
+cnt = collections.Counter(key[m].tolist())
+print("distinct SIMDs hosting LK waves:", len(cnt), " LK waves per SIMD histogram:", sorted(collections.Counter(cnt.values()).items()))
+ends = us[sl][m][:, 1]
+by = collections.defaultdict(list)
+for k, e in zip(key[m].tolist(), ends.tolist()):
+    by[k].append(e)
+for nw in sorted(set(cnt.values())):
+    last = [max(v) for k, v in by.items() if len(v) == nw]
+    print(f"  SIMDs with {nw} LK waves: {len(last)}, last LK end median {np.median(last):.1f} max {max(last):.1f} us")
