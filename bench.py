@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--borrow", action="store_true",
+                    help="stream path: ofx_params.borrow_frames (no level-0 copy; the resident frames are read in place)")
     ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 4],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
@@ -126,7 +128,7 @@ def main():
         if args.iters > 1:
             args.path = "plain"
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
-                              stream_batch=args.batch if args.path == "stream" else 1)
+                              stream_batch=args.batch if args.path == "stream" else 1, borrow_frames=args.borrow and args.path == "stream")
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
@@ -289,6 +291,24 @@ def main():
                 "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms2, 5),
                 "frames_per_s": round(1e3 / ms2, 1), "steps": n2}}
             s2.close()
+            if args.path == "stream" and not args.borrow:
+                # the same stream path without its own copy of level 0 (ofx_params.borrow_frames: the caller keeps every frame
+                # unmodified for 3 * batch further submits -- true of this resident ring)
+                s3 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=args.batch, borrow_frames=True)
+                s3.stream_begin()
+                for i in range(12):
+                    s3.stream_submit(d_frames[i % nframes])
+                torch.cuda.synchronize()
+                n3 = max(40, min(args.steps, 200))
+                t0 = time.perf_counter()
+                for i in range(n3):
+                    s3.stream_submit(d_frames[i % nframes])
+                torch.cuda.synchronize()
+                ms3 = (time.perf_counter() - t0) / n3 * 1e3
+                out["extra"]["stream_with_borrowed_frames"] = {
+                    "workload": "as value, but level 0 is read from the resident frames in place (no copy)",
+                    "value": round(w * h / (ms3 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms3, 5), "steps": n3}
+                s3.close()
         if driver is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, h, levels, window)
         print(json.dumps(out), flush=True)

@@ -53,6 +53,8 @@ struct ofx_session {
     const uint8_t *held_frame[kMaxBatch]{};      // multi-frame stream tick: the frames waiting for the tick to fill
     int held_pitch[kMaxBatch]{};
     int n_held = 0;
+    const uint8_t *bframe[kSets]{}; // borrow_frames: the caller's buffer behind image set i (level 0 is read from there)
+    int bpitch[kSets]{};
     long reported = 0;                   // highest pair reported complete by the stream pipeline
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
@@ -652,12 +654,29 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     auto uvslot = [&](long pair) { return s->uv + (size_t)(pair % slots) * 2 * OFX_MAX_LEVELS; };
     auto set_of = [&](long frame) { return (int)(frame % sets); };
     const long last_frame = s->stream_frames >= 0 ? s->stream_frames - 1 : f0 + n_frames - 1;
+    // level k of a frame as the LK / corner stages see it: the session's plane, or (borrow_frames, level 0) the caller's buffer
+    auto plane_of = [&](long frame, int k) -> const uint8_t * {
+        const int set = set_of(frame);
+        if (k == 0 && s->p.borrow_frames) return s->bframe[set] + (size_t)s->buf0[0] * (size_t)s->bpitch[set];
+        return s->img[set][k];
+    };
+    auto patch_of = [&](long frame, int k) -> const uint8_t * {
+        const int set = set_of(frame);
+        return (k == 0 && s->p.borrow_frames) ? s->bframe[set] : s->pimg[set][k];
+    };
+    auto pitch_of = [&](long frame, int k, bool patch) {
+        if (k == 0 && s->p.borrow_frames) return s->bpitch[set_of(frame)];
+        return patch ? s->ppitch[k] : s->pitch[k];
+    };
     // the stages struct is several KB: keep it off the stack of callers with small stacks
     static thread_local ofx_stream_stages g;
     memset(&g, 0, sizeof g);
     for (int i = 0; i < n_frames; ++i) { // pyramid(frame f0 + i)
         OFX_REQUIRE(pitches[i] >= s->w[0] && (pitches[i] & 3) == 0 && ((uintptr_t)frames[i] & 3) == 0,
                     "ofx_session_stream_submit: frame must be 4-byte aligned with a pitch multiple of 4 and >= width");
+        if (s->p.borrow_frames && f0 + i >= 1)
+            OFX_REQUIRE(pitches[i] == s->bpitch[set_of(f0 + i - 1)] || (i > 0 && pitches[i] == pitches[i - 1]),
+                        "ofx_session_stream_submit: borrowed frames must all have the same pitch");
         ofx_pyramid_stage &P = g.pyr[g.n_pyr++];
         const int set = set_of(f0 + i);
         P.d_frame = frames[i];
@@ -681,6 +700,12 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                 P.patch_pitches[k] = s->ppitch[k];
             }
         }
+        if (s->p.borrow_frames) { // no copies of level 0: the later stages read the caller's buffer
+            s->bframe[set] = frames[i];
+            s->bpitch[set] = pitches[i];
+            P.d_levels[0] = nullptr;
+            P.d_patch_levels[0] = nullptr;
+        }
     }
     for (long pc = f0 - B; pc <= f0 - 1; ++pc) { // corner(pair pc): both pyramids complete since the previous tick
         if (pc < 1 || pc > last_frame) continue;
@@ -688,12 +713,15 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         C.levels = L;
         C.d_uv = uvslot(pc);
         for (int k = 0; k < L; ++k) {
+            // (both frames of a pair come through the same API with the same pitch; a borrowed level 0 uses the caller's)
             if (s->p.local_corner) {
-                ofx_geom pg{s->w[k], s->h[k], s->ppitch[k], 0, s->ph[k], 0, s->ph[k]};
-                C.level[k] = ofx_lk_desc{s->pimg[set_of(pc - 1)][k], s->pimg[set_of(pc)][k], pg, nullptr, 0, nullptr, 0};
+                ofx_geom pg{s->w[k], s->h[k], pitch_of(pc, k, true), 0, s->ph[k], 0, s->ph[k]};
+                C.level[k] = ofx_lk_desc{patch_of(pc - 1, k), patch_of(pc, k), pg, nullptr, 0, nullptr, 0};
                 C.cols[k] = s->pw[k];
             } else {
-                C.level[k] = ofx_lk_desc{s->img[set_of(pc - 1)][k], s->img[set_of(pc)][k], level_geom(s, k, 0, s->h[k]), nullptr, 0, nullptr, 0};
+                ofx_geom cg = level_geom(s, k, 0, s->h[k]);
+                cg.pitch = pitch_of(pc, k, false);
+                C.level[k] = ofx_lk_desc{plane_of(pc - 1, k), plane_of(pc, k), cg, nullptr, 0, nullptr, 0};
             }
         }
         if (s->p.local_corner) C.d_status = s->corner_status;
@@ -702,9 +730,11 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
         if (pl < 1 || pl > last_frame) continue;
         float *const *fl = s->flowset[pl % B];
-        for (int k = L - 1; k >= 0; --k)
-            g.lk[g.n_lk++] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->img[set_of(pl)][k], level_geom(s, k, s->own0[k], s->own1[k]),
-                                         fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0};
+        for (int k = L - 1; k >= 0; --k) {
+            ofx_geom lg = level_geom(s, k, s->own0[k], s->own1[k]);
+            lg.pitch = pitch_of(pl, k, false);
+            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0};
+        }
         newest = pl;
     }
     *completed_pair = -1;

@@ -45,7 +45,7 @@ class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
-                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1):
+                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
@@ -53,6 +53,7 @@ class Session:
         p.iters = iters
         p.local_corner, p.patch_size = int(bool(local_corner)), int(patch_size)
         p.stream_batch = int(stream_batch)
+        p.borrow_frames = int(bool(borrow_frames))
         self.shard = shard
         if shard is not None:
             p.sharded = 1

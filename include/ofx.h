@@ -299,7 +299,14 @@ typedef struct ofx_params {
     /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 = one launch per two / four frames
      * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
-    int reserved[4];
+    /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame
+     * buffers handed to ofx_session_stream_submit, and the pyramid stage only writes levels 1 and up.  The caller must
+     * then keep every submitted frame buffer valid AND UNMODIFIED until the flow of the pair that starts at that frame
+     * has been reported complete, i.e. for 3 * stream_batch further submits (a ring of capture / decoder surfaces).
+     * Saves 2 bytes per level-0 pixel of HBM traffic per frame (at 4K: 13 % of a four-frame tick, most of it the
+     * write-back of the copy's dirty lines between launches).  0 = copy (any buffer lifetime). */
+    int borrow_frames;
+    int reserved[3];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);

@@ -444,21 +444,27 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 
-@pytest.mark.parametrize("batch", [2, 4])
+@pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (1, True), (4, True)])
 @pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
-                                 (640, 480, 6, 9, "lk_float", 1, 14)])
-def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch):
+                                 (640, 480, 6, 9, "lk_float", 1, 14), (250, 186, 2, 7, "lk_float", 1, 7)])
+def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch, borrow):
     """ofx_params.stream_batch = B: one launch per B frames (the LK items of B pairs share a launch: taller strips, 1/B of
     the launches).  Only every B-th call launches; pairs complete B at a time and are read through ofx_session_flow_of.
     Every pair must carry the bits of the plain sequence -- also for row-sharded sessions with local corner flows (third
     config: 4 logical ranks) and for frame counts that are not a multiple of B (the tail goes out when the stream is
-    drained)."""
+    drained).  borrow: ofx_params.borrow_frames -- no level-0 copy, the LK and corner stages read the frame buffers
+    (padded, dirty padding) in place."""
     import torch
     from cuda_optical_flow_2_amd.parallel import ShardPlan
 
     w, h, L, win, mode, R, nf = cfg
     B = batch
-    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.2 * i, -0.6 * i, seed=41)[1]).cuda() for i in range(nf)]
+    pitch = (w + 3) // 4 * 4 + 8
+    def padded(a):
+        buf = torch.full((h, pitch), 0x5A, dtype=torch.uint8, device="cuda")
+        buf[:, :w] = torch.from_numpy(a).cuda()
+        return buf[:, :w]
+    frames = [padded(synth.smooth_pair(w, h, 1.2 * i, -0.6 * i, seed=41)[1]) for i in range(nf)]
     plain = eng.Session(w, h, L, win, mode)
     plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
     want = {}
@@ -470,9 +476,10 @@ def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch):
     plain.close()
 
     if R == 1:
-        ranks = [eng.Session(w, h, L, win, mode, stream_batch=B)]
+        ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow)]
     else:
-        ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B) for r in range(R)]
+        ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B,
+                             borrow_frames=borrow) for r in range(R)]
     got = {}
     for s in ranks:
         s.stream_begin()
