@@ -63,8 +63,8 @@ def cpu_baseline(workload, w, h, levels, window):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
     ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
@@ -181,6 +181,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed clock ramp: the first ~10 ms of a kernel stream run 15-20 % slower than the sustained rate on MI355X (a
+    # 200-step run right after start-up measured 175-180k Mpix/s, the same steps after 0.1 s of load 210k+), and the default
+    # timed region is only tens of ms long.  So the device first works for OFX_BENCH_RAMP_S seconds on the very steps that
+    # are measured afterwards; then come the W warm-up steps and the K timed steps of the contract.
+    ramp_s = float(os.environ.get("OFX_BENCH_RAMP_S", "0.3"))
+    t_ramp = time.perf_counter() + ramp_s
+    i_ramp = 0
+    while time.perf_counter() < t_ramp:
+        for _ in range(64):
+            step(i_ramp)
+            i_ramp += 1
+        torch.cuda.synchronize()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -247,6 +259,7 @@ def main():
             "dtype": "i32/f64",
             "data": "synthetic",
             "config": {
+                "untimed_clock_ramp_s": ramp_s,
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
