@@ -80,6 +80,10 @@ def main():
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
     args = ap.parse_args()
+    # A stream tick carries `batch` frames and a step is one frame: the timed K steps (and the W warm-up steps before them)
+    # must be whole ticks, or frames would be counted that were only queued.  Use the largest batch that divides both.
+    while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch):
+        args.batch //= 2
 
     import numpy as np
     import torch
