@@ -76,6 +76,9 @@ def main():
                     help="stream path: ofx_params.borrow_frames (no level-0 copy; the resident frames are read in place)")
     ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 4],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame")
+    ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
+                    help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
+                         "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
@@ -163,8 +166,10 @@ def main():
         # One pair row-sharded over the ranks (strong scaling).  Default: every rank runs the one-launch-per-frame stream
         # pipeline on its row block with the corner flows computed from its own top-left patch -- no collective on the data
         # path; --shard-corner broadcast keeps rank 0's corner kernel + one RCCL broadcast per pair (staged halves).
+        if args.shard_halo == "exchange":
+            args.shard_corner = "broadcast"
         driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner,
-                                      stream_batch=args.batch)
+                                      stream_batch=args.batch, halo_mode=args.shard_halo)
         sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
@@ -271,7 +276,9 @@ def main():
                     f"row blocks over {world} rank(s), halos recomputed from a wider level-0 halo; " +
                     ("every rank runs the one-launch stream pipeline on its block and forms the shift vectors from its own top-left "
                      "patch of the frame: no collective on the data path (DESIGN.md section 5)" if sharded_stream else
-                     "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)")),
+                     "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)"))
+                    .replace("halos recomputed from a wider level-0 halo", "halo rows of every level exchanged with the neighbouring ranks"
+                             if args.shard_halo == "exchange" else "halos recomputed from a wider level-0 halo"),
             },
             "roofline": {
                 "bound": "hbm", "kernel": (f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "

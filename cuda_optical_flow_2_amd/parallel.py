@@ -45,6 +45,7 @@ class ShardPlan:
     rank: int
     world: int
     margin: int = 8  # rows of slack for the reference's global shift (|v| <= margin keeps the shift exact)
+    halo_mode: str = "recompute"  # "recompute": halos rebuilt from a wider level-0 halo; "exchange": fetched from the neighbours
     own: List[Range] = field(default_factory=list)   # rows whose flow this rank computes
     need: List[Range] = field(default_factory=list)  # rows of the images LK + shift may touch
     comp: List[Range] = field(default_factory=list)  # rows this rank downsamples itself (levels >= 1)
@@ -77,6 +78,18 @@ class ShardPlan:
             self.comp[k] = (lo, hi)
         if L == 1:
             self.comp[0] = self.buf[0] = self.need[0]
+        if self.halo_mode == "exchange":
+            # every level holds exactly what LK needs; a rank downsamples its own rows only and the halo rows of every
+            # level come from the neighbouring ranks (north_star's "halo exchange at each pyramid level")
+            self.buf = list(self.need)
+            self.comp = list(self.own)
+            for k in range(L):
+                rows = self.own[k][1] - self.own[k][0]
+                if self.world > 1 and rows < halo:
+                    raise ValueError(f"level {k}: a rank owns {rows} rows, fewer than the halo of {halo}: its neighbours would need rows "
+                                     "from two ranks away (use fewer ranks or the recompute mode)")
+        elif self.halo_mode != "recompute":
+            raise ValueError(f"halo_mode {self.halo_mode!r}")
 
     def redundancy(self) -> float:
         """Fraction of extra level-0 rows held beyond the owned block (the price of exchanging nothing per level)."""
@@ -138,6 +151,14 @@ class HipBackend:
     def build_pyramid(self):
         self.session.build_pyramid()
 
+    def downsample_level(self, level: int):
+        self.session.downsample_level(level)
+
+    def next_plane(self, level: int):
+        """(tensor [buffer rows, >= width], global index of its first row) of the frame being loaded."""
+        t, g = self.session.plane(1, level)
+        return t, g.row0
+
     def corner_flows(self):
         self.session.corner_flows()
 
@@ -155,9 +176,10 @@ class ShardedFlow:
     """One frame pair per step(), row-sharded over the ranks of the default process group."""
 
     def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True,
-                 corner="broadcast", patch_size=0, stream_batch=1):
+                 corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute"):
         assert corner in ("broadcast", "local")
-        self.plan = ShardPlan(width, height, levels, window, rank, world, margin)
+        assert halo_mode == "recompute" or corner == "broadcast", "the exchange mode is pair-at-a-time (rank 0's corner + broadcast)"
+        self.plan = ShardPlan(width, height, levels, window, rank, world, margin, halo_mode)
         self.rank, self.world, self.pipelined, self.corner = rank, world, pipelined, corner
         self.backend = backend if backend is not None else HipBackend(self.plan, mode, device, corner == "local", patch_size,
                                                                       stream_batch)
@@ -179,8 +201,54 @@ class ShardedFlow:
         """Make `frame` the previous frame (priming, main.cu:203-209)."""
         b = self.backend
         b.load_frame(frame)
-        b.build_pyramid()
+        self._build_pyramid()
         b.swap()
+
+    # ---- halo exchange (halo_mode == "exchange") -------------------------------------------------------------------
+    def _build_pyramid(self):
+        b = self.backend
+        if self.plan.halo_mode != "exchange":
+            b.build_pyramid()
+            return
+        # only this rank's own rows of the frame count (the rest of what load_frame brought in is overwritten here):
+        # level by level, own rows -> neighbours' halos, then the next level's own rows from them
+        self.exchange_halos(0)
+        for k in range(1, self.plan.levels):
+            b.downsample_level(k)
+            self.exchange_halos(k)
+
+    def exchange_halos(self, level: int):
+        """Fill the halo rows of `level`'s next plane from the neighbouring ranks' own rows (one batched send/recv pair
+        per neighbour: RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+        import torch.distributed as dist
+
+        if self.world == 1:
+            return
+        p = self.plan
+        plane, base = self.backend.next_plane(level)
+        w = p.width >> level
+        (o0, o1), (b0, b1) = p.own[level], p.buf[level]
+        ops, keep = [], []
+        if self.rank > 0:  # upper neighbour: it needs my first rows, I need its last ones
+            up = ShardPlan(p.width, p.height, p.levels, p.window, self.rank - 1, self.world, p.margin, p.halo_mode)
+            n_send = up.buf[level][1] - up.own[level][1]      # rows it holds below its block = my rows [o0, o0 + n_send)
+            n_recv = o0 - b0
+            snd = plane[o0 - base: o0 - base + n_send, :w].contiguous()
+            rcv = plane.new_empty((n_recv, w))
+            ops += [dist.P2POp(dist.isend, snd, self.rank - 1), dist.P2POp(dist.irecv, rcv, self.rank - 1)]
+            keep.append((rcv, b0, n_recv))
+        if self.rank + 1 < self.world:
+            dn = ShardPlan(p.width, p.height, p.levels, p.window, self.rank + 1, self.world, p.margin, p.halo_mode)
+            n_send = dn.own[level][0] - dn.buf[level][0]      # rows it holds above its block = my rows [o1 - n_send, o1)
+            n_recv = b1 - o1
+            snd = plane[o1 - n_send - base: o1 - base, :w].contiguous()
+            rcv = plane.new_empty((n_recv, w))
+            ops += [dist.P2POp(dist.isend, snd, self.rank + 1), dist.P2POp(dist.irecv, rcv, self.rank + 1)]
+            keep.append((rcv, o1, n_recv))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for rcv, row, n in keep:
+            plane[row - base: row - base + n, :w] = rcv
 
     def step(self, frame, check_margin: bool = False):
         """Flow between the previous frame and `frame`; afterwards `frame` is the previous frame."""
@@ -195,11 +263,11 @@ class ShardedFlow:
             b.run_levels()
             b.swap()
             return
-        if self.pipelined and not check_margin and hasattr(b, "pipelined_step"):
+        if self.pipelined and not check_margin and hasattr(b, "pipelined_step") and self.plan.halo_mode != "exchange":
             b.pipelined_step(frame, self.rank, self.world)
             return
         b.load_frame(frame)
-        b.build_pyramid()
+        self._build_pyramid()
         if self.rank == 0:
             b.corner_flows()  # needs only rank 0's own corner of every level
         if self.world > 1:

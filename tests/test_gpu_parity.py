@@ -264,6 +264,65 @@ def test_sharded_sessions_on_one_device(eng, mode):
 
 
 @pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_halo_exchange_sessions_on_one_device(eng, mode):
+    """halo_mode="exchange" on HIP sessions: every logical rank is handed ONLY its own rows of a frame (the rest is poison),
+    downsamples only its own rows (ofx_session_downsample_level with comp == own) and gets the halo rows of every level
+    from its neighbours' planes -- device copies here, where ShardedFlow.exchange_halos posts the RCCL send/recv pairs
+    (tests/test_parallel.py runs that code under gloo).  Bit-exact against the unsharded session."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import HipBackend, ShardPlan
+
+    w, h, L, win, R = 640, 960, 4, 9, 4   # 120 coarse rows: 30 per rank >= halo (4 + 1 + 8)
+    frames = [synth.smooth_pair(w, h, 1.5 * i, 0.75 * i, seed=3)[1] for i in range(3)]
+    whole = eng.Session(w, h, L, win, mode)
+    plans = [ShardPlan(w, h, L, win, r, R, 8, "exchange") for r in range(R)]
+    ranks = [HipBackend(pl, mode, 0) for pl in plans]
+
+    def load_and_build(i):
+        for pl, b in zip(plans, ranks):
+            seen = np.full_like(frames[i], 0xEE)
+            seen[pl.own[0][0]: pl.own[0][1]] = frames[i][pl.own[0][0]: pl.own[0][1]]
+            b.load_frame(torch.from_numpy(seen).cuda())
+        for k in range(L):
+            if k > 0:
+                for b in ranks:
+                    b.downsample_level(k)
+            views = [b.next_plane(k) for b in ranks]
+            wk = w >> k
+            for r, (pl, (t, base)) in enumerate(zip(plans, views)):   # halos from the neighbours' OWN rows
+                (o0, o1), (b0, b1) = pl.own[k], pl.buf[k]
+                if r > 0:
+                    src, sbase = views[r - 1]
+                    t[b0 - base: o0 - base, :wk] = src[b0 - sbase: o0 - sbase, :wk]
+                if r + 1 < R:
+                    src, sbase = views[r + 1]
+                    t[o1 - base: b1 - base, :wk] = src[o1 - sbase: b1 - sbase, :wk]
+
+    whole.set_frame_device(torch.from_numpy(frames[0]).cuda()); whole.build_pyramid(); whole.swap()
+    load_and_build(0)
+    for b in ranks:
+        b.swap()
+    for i in (1, 2):
+        whole.set_frame_device(torch.from_numpy(frames[i]).cuda()); whole.build_pyramid(); whole.run_flow()
+        load_and_build(i)
+        ranks[0].corner_flows()
+        for b in ranks[1:]:
+            b.uv_all.copy_(ranks[0].uv_all)
+        for b in ranks:
+            b.run_levels()
+        torch.cuda.synchronize()
+        for k in range(L):
+            got = torch.cat([b.flow(k) for b in ranks], dim=0).cpu().numpy()
+            assert_same(got, whole.flow_host(k), f"{mode} frame {i} level {k}")
+        whole.swap()
+        for b in ranks:
+            b.swap()
+    whole.close()
+    for b in ranks:
+        b.session.close()
+
+
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
 def test_pipelined_submit_equals_plain_sequence(eng, mode):
     """submit_device (staging on the aux stream under the previous LK launch, three rotating image sets) must give, for
     EVERY pair of a back-to-back stream, the bits of set_frame/build_pyramid/run_flow/swap.  Flow snapshots are taken with

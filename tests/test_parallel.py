@@ -126,6 +126,28 @@ class OracleBackend:
             self.next[k] = out[c0 - s0 // 2:].copy()
             assert self.next[k].shape[0] == c1 - c0
 
+    def downsample_level(self, k):
+        """Exchange mode: this rank's OWN rows of level k from level k-1 (own rows + the halo row above them)."""
+        p = self.plan
+        c0, c1 = p.comp[k]
+        assert (c0, c1) == p.own[k]
+        s0, s1 = max(0, 2 * c0 - 2), 2 * c1
+        src0 = p.buf[k - 1][0]
+        crop = np.zeros((s1 - s0, self.w[k - 1]), np.uint8)
+        lo = max(s0, src0)
+        assert s1 <= p.buf[k - 1][1] and lo <= max(0, 2 * c0 - 1)
+        crop[lo - s0:] = self.next[k - 1][lo - src0: s1 - src0]
+        out = self.orc.downscale_gaussian(synth.to_3ch(crop))[:, :, 0]
+        b0, b1 = p.buf[k]
+        if self.next[k] is None:
+            self.next[k] = np.full((b1 - b0, self.w[k]), 0xEE, np.uint8)   # halo rows: poison until the exchange fills them
+        self.next[k][c0 - b0: c1 - b0] = out[c0 - s0 // 2:]
+
+    def next_plane(self, k):
+        import torch
+
+        return torch.from_numpy(self.next[k]), self.plan.buf[k][0]
+
     def _shift_rows(self, k, u, v, y0, y1):
         """cpu::shift_back_pyramid on channel 0 for global rows [y0,y1) of level k, from this rank's buffer only."""
         w, h, b0 = self.w[k], self.h[k], self.plan.buf[k][0]
@@ -203,7 +225,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _rank_main(rank, world, port, cfg, mode, corner="broadcast"):
+def _rank_main(rank, world, port, cfg, mode, corner="broadcast", halo_mode="recompute"):
     import torch.distributed as dist
     from conftest import assert_same
     from oracle import Oracle
@@ -214,13 +236,23 @@ def _rank_main(rank, world, port, cfg, mode, corner="broadcast"):
     try:
         w, h, L, win, margin = cfg
         frames = [synth.smooth_pair(w, h, 1.5 * i, 0.75 * i, seed=5)[1] for i in range(3)]
-        plan = ShardPlan(w, h, L, win, rank, world, margin)
+        plan = ShardPlan(w, h, L, win, rank, world, margin, halo_mode)
         sf = ShardedFlow(w, h, L, win, mode, rank, world, margin=margin, backend=OracleBackend(plan, mode, patch_size=48),
-                         corner=corner)
-        sf.push_frame(frames[0])
+                         corner=corner, halo_mode=halo_mode)
+
+        def seen_by_rank(frame):
+            """Exchange mode: a rank only has its own rows of a frame; everything else is poison it must never use."""
+            if halo_mode != "exchange":
+                return frame
+            f = np.full_like(frame, 0xEE)
+            o0, o1 = plan.own[0]
+            f[o0:o1] = frame[o0:o1]
+            return f
+
+        sf.push_frame(seen_by_rank(frames[0]))
         orc = Oracle()
         for i in (1, 2):
-            sf.step(frames[i], check_margin=corner == "broadcast")
+            sf.step(seen_by_rank(frames[i]), check_margin=corner == "broadcast")
             want, _, _ = orc.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), L, win, mode, exact_sums=True)
             for k in range(L):
                 got = sf.gather_flow(k).numpy()
@@ -246,3 +278,25 @@ def test_sharded_flow_gloo_local_corner(mode):
 
     cfg = (96, 144, 3, 5, 8)
     mp.spawn(_rank_main, args=(2, _free_port(), cfg, mode, "local"), nprocs=2, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_sharded_flow_gloo_halo_exchange(world, mode):
+    """halo_mode="exchange" (north_star's formulation): a rank is given ONLY its own rows of each frame (the rest is
+    poisoned), downsamples only its own rows, and fetches the halo rows of every pyramid level from its neighbours with
+    one batched send/recv per neighbour and level; rank 0's shift vectors are broadcast.  Bit-exact against the
+    unsharded oracle."""
+    import torch.multiprocessing as mp
+
+    cfg = (96, 288, 3, 5, 4)  # 72 coarse rows: every rank owns >= the halo (3 + 4) rows at every level, also with 3 ranks
+    mp.spawn(_rank_main, args=(world, _free_port(), cfg, mode, "broadcast", "exchange"), nprocs=world, join=True)
+
+
+def test_exchange_plan_invariants():
+    for world in (2, 4, 8):
+        plans = [ShardPlan(3840, 2160, 5, 9, r, world, 8, "exchange") for r in range(world)]
+        for p in plans:
+            assert p.comp == p.own and p.buf == p.need
+    with pytest.raises(ValueError):
+        ShardPlan(96, 144, 3, 5, 0, 4, 8, "exchange")   # 9 coarse rows per rank < halo 11: a neighbour's halo would span two ranks
