@@ -220,6 +220,29 @@ def main():
     k_avg_us, k_min_us, k_n = sess.timing_read()
     sess.timing(0)
 
+    # N > 1 only, reported under `extra`: the other way to use N GPUs on a frame stream -- every rank runs the unsharded
+    # pipeline on its own pairs (no sharding, nothing shared): N times the pairs per second at unchanged latency per pair.
+    # Same step count, same fences, max over ranks.
+    dt_indep = None
+    if driver is not None:
+        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=args.batch)
+        s4.stream_begin()
+        t_ramp = time.perf_counter() + 0.1
+        while time.perf_counter() < t_ramp:
+            for i in range(64):
+                s4.stream_submit(d_frames[i % nframes])
+            torch.cuda.synchronize()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            s4.stream_submit(d_frames[i % nframes])
+        fence()
+        dt_indep = time.perf_counter() - t0
+        s4.close()
+        t4 = torch.tensor([dt_indep], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+        dt_indep = float(t4.item())
+
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1 or force_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -333,6 +356,13 @@ def main():
                     "workload": "as value, but level 0 is read from the resident frames in place (no copy)",
                     "value": round(w * h / (ms3 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms3, 5), "steps": n3}
                 s3.close()
+        if dt_indep is not None:
+            ms4 = dt_indep / args.steps * 1e3
+            out.setdefault("extra", {})["independent_pairs_per_rank"] = {
+                "workload": f"every one of the {world} rank(s) runs the unsharded stream pipeline on its own frame pairs (no sharding, no "
+                            "communication): aggregate pairs/s, weak scaling, latency per pair as on one GPU",
+                "value": round(world * w * h / (ms4 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step_per_rank": round(ms4, 5),
+                "steps_per_rank": args.steps}
         if driver is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, w, h, levels, window)
         print(json.dumps(out), flush=True)
