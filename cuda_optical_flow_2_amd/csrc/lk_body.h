@@ -125,31 +125,56 @@ __device__ __forceinline__ int lane_from(int x)
     }
 }
 
+// acc + (the value of x held D lanes away), for the horizontal box.  The LAST one-lane shift is left unfenced and the sum
+// is kept a two-operand add (the fence after it stops the compiler from merging two of them into a v_add3_u32, which
+// cannot carry a DPP operand), so that the combiner folds move and add into ONE v_add_u32_dpp -- 2 instructions per
+// neighbour term instead of 3 for two.  Addition is commutative, so the operand mix-up that broke the subtract form
+// (above) cannot change the result.  OFX_LK_FOLD_DPP_ADDS=0 restores the fenced moves + add3.
+#ifndef OFX_LK_FOLD_DPP_ADDS
+#define OFX_LK_FOLD_DPP_ADDS 1
+#endif
+template <int D>
+__device__ __forceinline__ int add_from(int acc, int x)
+{
+    if constexpr (D == 0) {
+        return acc + x;
+    } else {
+#if OFX_LK_FOLD_DPP_ADDS
+        const int near = lane_from<(D > 0 ? D - 1 : D + 1)>(x); // all but the last lane step: fenced moves
+        int r = acc + __builtin_amdgcn_update_dpp(0, near, D > 0 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        asm volatile("" : "+v"(r));
+        return r;
+#else
+        return acc + lane_from<D>(x);
+#endif
+    }
+}
+
 // ---- horizontal box sum over columns [c-R, c+R] for the 4 columns of a lane -------------------------------
-// q[k] = a0+..+ak, s[k] = ak+..+a3 (q[3] == s[0] == lane total).
+// q[k] = a0+..+ak, s[k] = ak+..+a3 (q[3] == s[0] == lane total).  Each helper adds its lanes' terms to acc.
 template <int R, int I, int D>
-__device__ __forceinline__ int hbox_right(const int (&q)[4])
+__device__ __forceinline__ int hbox_right(const int (&q)[4], int acc)
 {
     constexpr int hi = I + R; // last relative column of the window; lane +D holds relative columns 4D..4D+3
     if constexpr (hi < 4 * D) {
-        return 0;
+        return acc;
     } else if constexpr (hi >= 4 * D + 3) {
-        return lane_from<D>(q[3]) + hbox_right<R, I, D + 1>(q);
+        return hbox_right<R, I, D + 1>(q, add_from<D>(acc, q[3]));
     } else {
-        return lane_from<D>(q[hi - 4 * D]);
+        return add_from<D>(acc, q[hi - 4 * D]);
     }
 }
 
 template <int R, int I, int D>
-__device__ __forceinline__ int hbox_left(const int (&s)[4])
+__device__ __forceinline__ int hbox_left(const int (&s)[4], int acc)
 {
     constexpr int lo = I - R; // first relative column; lane -D holds relative columns -4D..-4D+3
     if constexpr (lo > -4 * D + 3) {
-        return 0;
+        return acc;
     } else if constexpr (lo <= -4 * D) {
-        return lane_from<-D>(s[0]) + hbox_left<R, I, D + 1>(s);
+        return hbox_left<R, I, D + 1>(s, add_from<-D>(acc, s[0]));
     } else {
-        return lane_from<-D>(s[lo + 4 * D]);
+        return add_from<-D>(acc, s[lo + 4 * D]);
     }
 }
 
@@ -166,7 +191,7 @@ __device__ __forceinline__ int hbox_one(const int (&q)[4], const int (&s)[4])
     } else {
         own = q[ohi] - q[olo - 1];
     }
-    return own + hbox_right<R, I, 1>(q) + hbox_left<R, I, 1>(s);
+    return hbox_left<R, I, 1>(s, hbox_right<R, I, 1>(q, own));
 }
 
 template <int R>
