@@ -16,7 +16,7 @@
 // v_rcp_f64 seed, one Newton step to ~1 ulp, then Markstein's correction r = fma(-x,p,1); p = fma(p,r,p), which
 // yields the correctly rounded quotient (the only exception, an all-ones significand, needs |x| >= 2^52).  x == 0
 // gives +-Inf like the IEEE division the reference performs.  8 instructions instead of the ~13 of the generic
-// division expansion (div_scale/div_fmas/div_fixup handle ranges that cannot occur here).
+// division expansion (div_scale/div_fmas handle ranges that cannot occur here).
 __device__ __forceinline__ double recip_f64(double x)
 {
     double p = __builtin_amdgcn_rcp(x);
@@ -26,7 +26,9 @@ __device__ __forceinline__ double recip_f64(double x)
     p = __builtin_fma(p, e, p);
     e = __builtin_fma(-x, p, 1.0);
     p = __builtin_fma(p, e, p);
-    return x == 0.0 ? __builtin_copysign(__builtin_inf(), x) : p;
+    // x == 0: the Newton steps turned the +-Inf seed into NaN; v_div_fixup_f64 puts the IEEE special cases of 1/x back
+    // (+-Inf for +-0) and passes every other quotient through -- one instruction instead of a compare and two selects
+    return __builtin_amdgcn_div_fixup(p, x, 1.0);
 }
 
 template <int MODE>
