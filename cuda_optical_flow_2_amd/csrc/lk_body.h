@@ -52,6 +52,21 @@ __device__ __forceinline__ uint32_t lane_off(uint32_t off)
     asm volatile("" : "+v"(off));
     return off;
 }
+// the same for an offset the caller keeps in a variable of its own for the whole march: the variable itself is made opaque,
+// so no copy of it is needed per access (by value, the asm's output needs a register of its own: one v_mov per load)
+__device__ __forceinline__ uint32_t lane_off_var(uint32_t &off)
+{
+    asm volatile("" : "+v"(off));
+    return off;
+}
+__device__ __forceinline__ uint32_t gload_u32_var(const uint8_t *base, uint32_t &off)
+{
+    return *(const OFX_GLOBAL uint32_t *)((const OFX_GLOBAL uint8_t *)base + lane_off_var(off));
+}
+__device__ __forceinline__ uint32_t gload_u32_unaligned_var(const uint8_t *base, uint32_t &off)
+{
+    return ((const OFX_GLOBAL UnalignedU32 *)((const OFX_GLOBAL uint8_t *)base + lane_off_var(off)))->v;
+}
 __device__ __forceinline__ uint32_t gload_u32(const uint8_t *base, uint32_t off)
 {
     return *(const OFX_GLOBAL uint32_t *)((const OFX_GLOBAL uint8_t *)base + lane_off(off));
@@ -62,6 +77,11 @@ __device__ __forceinline__ uint32_t gload_u32_unaligned(const uint8_t *base, uin
 }
 typedef OFX_GLOBAL float *gfloat_ptr;
 __device__ __forceinline__ gfloat_ptr gptr_f32(float *base, uint32_t idx) { return (gfloat_ptr)base + lane_off(idx); }
+// base + a BYTE offset kept by the caller (see lane_off_var): selects as scalar base + 32-bit lane offset
+__device__ __forceinline__ gfloat_ptr gptr_f32_var(float *base, uint32_t &byte_off)
+{
+    return (gfloat_ptr)((OFX_GLOBAL uint8_t *)base + lane_off_var(byte_off));
+}
 // the flow is written once and never read back by this launch: streaming stores keep it from displacing the image rows
 // the trailing window re-reads from L2
 __device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b)
@@ -351,8 +371,8 @@ __device__ __forceinline__ s2 lane_shift_s2(s2 v, bool from_left)
 
 __device__ __forceinline__ s2 pk_two()
 {
-    uint32_t v = 0x00020002u;
-    asm volatile("" : "+v"(v));
+    uint32_t v = 0x00020002u; // opaque (2,2): keeps the [1 2 1] combinations as one v_pk_mad_u16 instead of shift + add
+    asm volatile("" : "+s"(v));
     return as_s2(v);
 }
 
@@ -411,14 +431,12 @@ __device__ __forceinline__ void unpack_pk(uint32_t pi, uint32_t ni, uint32_t po,
     r.n[3] = pair_bytes<3>(ni, no);
 }
 
-// derivatives of the middle rows of both windows; mk[j] = 16-bit-lane masks (column inside the image AND that window's
-// row inside the image and already part of the strip); only Ix and Iy are masked (every product has one as a factor)
+// derivatives of the middle rows of both windows, UNMASKED: pixels outside the image or the strip are removed by
+// accumulate_pk's multipliers.  `two` = pk_two(), made once per wave.
 __device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_LK_FLOAT> &t, const RowPk<OFX_MODE_LK_FLOAT> &m,
-                                          const RowPk<OFX_MODE_LK_FLOAT> &b, const uint32_t (&mk)[4], s2 (&ix)[4], s2 (&iy)[4],
-                                          s2 (&it)[4])
+                                          const RowPk<OFX_MODE_LK_FLOAT> &b, const s2 two, s2 (&ix)[4], s2 (&iy)[4], s2 (&it)[4])
 {
     s2 sm[6], df[6], g[6];
-    const s2 two = pk_two(); // opaque (2,2): keeps the [1 2 1] combinations as one v_pk_mad_i16 instead of shift + add
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         sm[j + 1] = m.p[j] * two + (t.p[j] + b.p[j]); // [1 2 1]^T (kernels.cpp:6-19)
@@ -433,15 +451,14 @@ __device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_LK_FLOAT> &t, con
     g[5] = lane_shift_s2(g[1], false);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        ix[j] = as_s2(as_u32(sm[j + 2] - sm[j]) & mk[j]);
-        iy[j] = as_s2(as_u32(df[j + 1] * two + (df[j] + df[j + 2])) & mk[j]);
+        ix[j] = sm[j + 2] - sm[j];
+        iy[j] = df[j + 1] * two + (df[j] + df[j + 2]);
         it[j] = g[j + 1] * two + (g[j] + g[j + 2]) - m.d[j];
     }
 }
 
 __device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_COMPAT_CPU> &t, const RowPk<OFX_MODE_COMPAT_CPU> &m,
-                                          const RowPk<OFX_MODE_COMPAT_CPU> &b, const uint32_t (&mk)[4], s2 (&ix)[4], s2 (&iy)[4],
-                                          s2 (&it)[4])
+                                          const RowPk<OFX_MODE_COMPAT_CPU> &b, const s2, s2 (&ix)[4], s2 (&iy)[4], s2 (&it)[4])
 {
     // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap contributes
     // floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64); u8 wrap (:106, :15)
@@ -465,7 +482,7 @@ __device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_COMPAT_CPU> &t, c
     sn[5] = lane_shift_s2(sn[1], false);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t m8 = mk[j] & 0x00ff00ffu;
+        constexpr uint32_t m8 = 0x00ff00ffu; // the (unsigned char) wrap of OptFlowCPU.cpp:106
         ix[j] = as_s2(as_u32(sm[j + 2] - sm[j]) & m8);
         iy[j] = as_s2(as_u32((df[j + 1] + df[j + 1]) + df[j] + df[j + 2]) & m8);
         const s2 gp = sp[j] + mp[j] + sp[j + 2], gn = sn[j] + mn[j] + sn[j + 2];
@@ -473,19 +490,23 @@ __device__ __forceinline__ void derivs_pk(const RowPk<OFX_MODE_COMPAT_CPU> &t, c
     }
 }
 
-// V += P(entering) - P(leaving) for the five products, order of the planes: OptFlowCPU.cpp:347-358
-__device__ __forceinline__ void accumulate_pk(const s2 (&ix)[4], const s2 (&iy)[4], const s2 (&it)[4], int (&vxx)[4], int (&vyy)[4],
-                                              int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
+// V += P(entering) - P(leaving) for the five products, order of the planes: OptFlowCPU.cpp:347-358.
+// mm[j] = per-column multiplier pair: low half 1 when the entering row's pixel counts (column inside the image, row inside
+// the image), high half -1 when the leaving row's pixel counts (... and that row has entered this strip), else 0.  One
+// v_pk_mul_lo_u16 by it both removes the pixels that do not count and negates the leaving row's factor; every product
+// below has nx or ny as a factor, so Ix, Iy and It themselves need no masking (rows and columns outside the image read as
+// zero bytes, so every value stays inside its 16-bit range).
+__device__ __forceinline__ void accumulate_pk(const s2 (&ix)[4], const s2 (&iy)[4], const s2 (&it)[4], const uint32_t (&mm)[4],
+                                              int (&vxx)[4], int (&vyy)[4], int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
 {
-    const s2 flip = {1, -1}; // negate the leaving row's factor
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const s2 nx = ix[j] * flip, ny = iy[j] * flip, nt = it[j] * flip;
+        const s2 nx = ix[j] * as_s2(mm[j]), ny = iy[j] * as_s2(mm[j]);
         vxx[j] = __builtin_amdgcn_sdot2(ix[j], nx, vxx[j], false);
         vyy[j] = __builtin_amdgcn_sdot2(iy[j], ny, vyy[j], false);
         vxy[j] = __builtin_amdgcn_sdot2(ix[j], ny, vxy[j], false);
-        vxt[j] = __builtin_amdgcn_sdot2(ix[j], nt, vxt[j], false);
-        vyt[j] = __builtin_amdgcn_sdot2(iy[j], nt, vyt[j], false);
+        vxt[j] = __builtin_amdgcn_sdot2(nx, it[j], vxt[j], false);
+        vyt[j] = __builtin_amdgcn_sdot2(ny, it[j], vyt[j], false);
     }
 }
 
@@ -569,7 +590,8 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         cm[j] = in ? -1 : 0;
         bmask |= in ? (0xffu << (8 * j)) : 0u;
     }
-    const uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
+    uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
+    uint32_t flow_off = 8u * (uint32_t)(cb > 0 ? cb : 0); // byte offset of this lane's first (u,v) pair in a flow row
 
     // rows outside the image are the zero border; rows past the last one this strip needs (the loop prefetches one
     // row ahead) or outside the buffer are never dereferenced.  The row test is wave-uniform (scalar branch); lanes
@@ -583,7 +605,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         if (y >= y_min && y < y_lim) {
             const uint8_t *row = img + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
             pin_scalar(row); // scalar base + 32-bit lane offset: no VALU address arithmetic
-            v = gload_u32(row, col_off);
+            v = gload_u32_var(row, col_off);
         }
         return v;
     };
@@ -635,24 +657,34 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         uint32_t own, sh; // the row's own dword / the dword at the shifted position (0 where not needed)
         uint32_t have;    // wave-uniform: ~0 when the shifted row exists
     };
+    // The row map y -> (int)((float)y + v) is wave-uniform but float arithmetic, i.e. VALU work (8 instructions per row,
+    // two rows per step).  It is evaluated for 64 consecutive rows at a time instead -- lane i holds the target of row
+    // map_base + i, or -1 when that target is outside the image or the buffer -- and a step reads its two entries with
+    // v_readlane_b32.  The march refreshes the table when the entering row runs off its end (refresh_map).
+    int map_base = 0, row_map = -1;
+    auto refresh_map = [&](int y0) {
+        map_base = y0;
+        const float ty = (float)(y0 + lane) + sv;
+        const bool yin = ty > -1.0f && ty < (float)A.h;
+        const int ny = yin ? (int)ty : 0;
+        row_map = (yin && ny >= A.row0 && ny < A.row_end) ? ny : -1;
+    };
     auto fetch_next = [&](int y) -> NextRaw {
         NextRaw r = {0u, 0u, 0u};
         if (y >= y_min && y < y_lim) {
-            const float ty = (float)y + sv;
-            const bool yin = ty > -1.0f && ty < (float)A.h;
-            const int ny = __builtin_amdgcn_readfirstlane(yin ? (int)ty : 0); // uniform: y and v are
-            const bool have = yin && ny >= A.row0 && ny < A.row_end;
+            const int ny = __builtin_amdgcn_readlane(row_map, y - map_base);
+            const bool have = ny >= 0;
             r.have = have ? ~0u : 0u;
             if (have) {
                 const uint8_t *srow = A.next + (size_t)(uint32_t)(ny - A.row0) * (size_t)(uint32_t)A.pitch;
                 pin_scalar(srow);
-                r.sh = gload_u32_unaligned(srow, nb_off);
+                r.sh = gload_u32_unaligned_var(srow, nb_off);
             }
             // interior tile with its target row inside the image: every byte comes from the shifted dword
             if (!(have && all_in) && y < y_none) {
                 const uint8_t *orow = A.next + (size_t)(uint32_t)(y - A.row0) * (size_t)(uint32_t)A.pitch;
                 pin_scalar(orow);
-                r.own = gload_u32(orow, col_off);
+                r.own = gload_u32_var(orow, col_off);
                 if (y == y_part) {
                     uint32_t km = 0u;
 #pragma unroll
@@ -685,9 +717,11 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     // NS steps later: its rows before y_first - 1 are fed as zeros and its derivative rows before y_first are masked,
     // so the strip's priming steps need no code of their own.
     RowPk<MODE> wp[3];
+    const s2 two = pk_two();
     // rows of the leaving window before y_first - 1 are zeros
     auto fetch_out_prev = [&](int r) -> uint32_t { return r < y_first - 1 ? 0u : fetch_row(A.prev, r); };
     auto fetch_out_next = [&](int r) -> NextRaw { return r < y_first - 1 ? NextRaw{0u, 0u, 0u} : fetch_next(r); };
+    refresh_map(y_first - 1);
     unpack_pk(load_row(A.prev, y_first - 1), load_next(y_first - 1), 0u, 0u, wp[0]);
     unpack_pk(load_row(A.prev, y_first), load_next(y_first), 0u, 0u, wp[1]);
     unpack_pk(load_row(A.prev, y_first + 1), load_next(y_first + 1), finish_row(fetch_out_prev(y_first + 1 - NS)),
@@ -703,6 +737,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         // Issue the loads of the rows the next step adds (yy + 2 and yo + 2).  They are finished (mask / permute / unpack)
         // at the end of this step, before its flow stores: gfx9 counts loads and stores in one vmcnt and only orders
         // returns within a type, so a wait for a load that has younger stores outstanding is a wait for those stores too.
+        if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
         const uint32_t pf_ip = fetch_row(A.prev, yy + 2), pf_op = fetch_out_prev(yo + 2);
         const NextRaw pf_in = fetch_next(yy + 2), pf_on = fetch_out_next(yo + 2);
         // a refinement launch adds to the flow already there: its 8 floats are fetched with the rows and waited for once
@@ -715,7 +750,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
             if (A.accumulate && emit && out_lane) {
                 float *frow = A.flow + 2 * rowpix;
                 pin_scalar(frow);
-                const gfloat_ptr src = gptr_f32(frow, 2u * (uint32_t)cb);
+                const gfloat_ptr src = gptr_f32_var(frow, flow_off);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (cb + j < A.w) old_uv[2 * j] = src[2 * j], old_uv[2 * j + 1] = src[2 * j + 1];
@@ -724,11 +759,11 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 
         // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
         // window only counts once its row has entered (yo >= y_first)
-        const uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x0000ffffu : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
-        const uint32_t mk[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
+        const uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
+        const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
         s2 ix[4], iy[4], it[4];
-        derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], mk, ix, iy, it);
-        accumulate_pk(ix, iy, it, vxx, vyy, vxy, vxt, vyt);
+        derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
+        accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
         // row yy - 1 is done with: its slot takes row yy + 2 once the step's arithmetic is over
         // (the barrier keeps the scheduler from hoisting these few ALU ops -- and with them the wait -- up to the loads;
         // pin_row keeps the sink passes from moving them down into the next step, below its loads)
@@ -741,6 +776,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 #else
     Row<MODE> win[3], wout[3];
     {
+        refresh_map(y_first - 1);
         const uint32_t p0 = load_row(A.prev, y_first - 1), n0 = load_next(y_first - 1);
         const uint32_t p1 = load_row(A.prev, y_first), n1 = load_next(y_first);
         unpack(p0, n0, win[0]);
@@ -761,6 +797,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
         const bool have_out = s >= NS;
 
         // take the prefetched rows, prefetch the next ones (consumed one step from now)
+        if (yy + 2 - map_base >= 64) refresh_map(have_out ? yo + 2 : yy + 2);
         unpack(pf_ip, pf_in, win[(k + 2) % 3]);
         pf_ip = load_row(A.prev, yy + 2);
         pf_in = load_next(yy + 2);
@@ -832,20 +869,23 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
             } else {
                 float *frow = A.flow + 2 * rowpix;
                 pin_scalar(frow);
-                const gfloat_ptr dst = gptr_f32(frow, 2u * (uint32_t)cb);
                 if constexpr (MAY_ACC) {
                     if (A.accumulate) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) uv[j] = old_uv[j] + uv[j];
                     }
                 }
+                // (the address is formed inside each branch: instruction selection only picks the scalar-base form when the
+                // offset's extension sits in the block of the access)
                 if (cb + 3 < A.w) {
                     // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
+                    const gfloat_ptr dst = gptr_f32_var(frow, flow_off);
                     gstore_f32x2(dst, uv[0], uv[1]);
                     gstore_f32x2(dst + 2, uv[2], uv[3]);
                     gstore_f32x2(dst + 4, uv[4], uv[5]);
                     gstore_f32x2(dst + 6, uv[6], uv[7]);
                 } else {
+                    const gfloat_ptr dst = gptr_f32_var(frow, flow_off);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (cb + j < A.w) {
