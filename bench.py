@@ -64,7 +64,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=104)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
     ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
@@ -74,8 +74,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--borrow", action="store_true",
                     help="stream path: ofx_params.borrow_frames (no level-0 copy; the resident frames are read in place)")
-    ap.add_argument("--batch", type=int, default=4, choices=[1, 2, 4],
-                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame")
+    ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8],
+                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = 4 on one GPU, "
+                         "8 when a pair is sharded over several (a rank's share of a pair is small next to a launch's fixed cost)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
                          "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
@@ -85,7 +86,10 @@ def main():
     args = ap.parse_args()
     # A stream tick carries `batch` frames and a step is one frame: the timed K steps (and the W warm-up steps before them)
     # must be whole ticks, or frames would be counted that were only queued.  Use the largest batch that divides both.
-    while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch):
+    if args.batch == 0:
+        args.batch = 8 if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else 4
+    while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch or
+                              args.batch * WORKLOADS[args.workload][2] > 40):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2
 
     import numpy as np
@@ -225,7 +229,8 @@ def main():
     # Same step count, same fences, max over ranks.
     dt_indep = None
     if driver is not None:
-        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=args.batch)
+        # (four frames per launch as at N = 1: eight only pay when a launch carries a fraction of a pair)
+        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=min(args.batch, 4))
         s4.stream_begin()
         t_ramp = time.perf_counter() + 0.1
         while time.perf_counter() < t_ramp:

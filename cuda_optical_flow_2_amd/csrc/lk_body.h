@@ -554,8 +554,13 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     constexpr int NS = 2 * R + 1;
 
     if (wave >= T.first_block[T.n]) return;
-    int level = 0;
-    while (level + 1 < T.n && wave >= T.first_block[level + 1]) ++level;
+    // the item this wave belongs to: the last one whose first_block <= wave (up to 40 items: bisection, 6 scalar loads)
+    int level = 0, hi = T.n;
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (wave >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
     // The level's arguments, held in SGPRs for the whole march: left as references into the kernarg table the compiler
     // re-reads them from memory inside the loop (~25 s_load + wait per step).
     LkArgs A = T.lv[level];

@@ -369,7 +369,7 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
 }
 
 // Debug / measurement hook (tools/stream_timeline.py): with a device buffer of 8 * capacity_blocks uint64 set, every
-// wave of every later ofx_stream_launch records its start and end time there; first[] (size 9) receives the block ranges of
+// wave of every later ofx_stream_launch records its start and end time there; first[] (2 * OFX_STREAM_MAX_BATCH + 1 ints) receives the block ranges of
 // the last launch.  d_buf = NULL switches it off.
 extern "C" int ofx_debug_stream_trace(unsigned long long *d_buf, int capacity_blocks, int *first)
 {

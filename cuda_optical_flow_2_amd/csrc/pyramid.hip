@@ -275,12 +275,12 @@ int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, ui
     // Strips.  A marching wave runs at top priority next to the LK waves of its SIMD and takes its instructions out of their
     // issue slots, so the waves should spread over the machine rather than pile work on a few SIMDs: the caller names the
     // number of waves it wants (about 0.85 per SIMD for all the pyramids of a tick); each strip pays 2^n priming rows, so
-    // a strip is at least twice that and at most 128 rows.
+    // a strip is at least twice that (and at most 128 rows when the caller names no target).
     const int span = a.y_hi - a.y_lo;
     const int want = target_waves > 0 ? target_waves : 16 * a.tiles_x;
     int sh = ofx_div_up(ofx_div_up(span * a.tiles_x, want), step) * step;
     sh = sh < 2 * step ? 2 * step : sh;
-    sh = sh > 128 ? 128 / step * step : sh;
+    if (target_waves <= 0) sh = sh > 128 ? 128 / step * step : sh; // (a named target is a budget of wave slots: never exceed it)
     a.strip_h = sh;
     a.strips = ofx_div_up(span, sh);
     *out = a;

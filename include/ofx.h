@@ -45,7 +45,7 @@ extern "C" {
                                  double solve */
 
 #define OFX_MAX_LEVELS 12
-#define OFX_MAX_LK_ITEMS 24 /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
+#define OFX_MAX_LK_ITEMS 40 /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
 
 const char *ofx_last_error(void);
 /* library/ABI version, bumped when a signature changes */
@@ -114,7 +114,7 @@ typedef struct ofx_shift_desc {
  * share one launch, which multiplies the strip height by B (1/B of the priming rows per output row) and divides the
  * number of launches by B.
  * ofx_session_stream_submit drives this; it is exposed for callers that manage their own buffers. */
-#define OFX_STREAM_MAX_BATCH 4
+#define OFX_STREAM_MAX_BATCH 8
 typedef struct ofx_pyramid_stage {
     /* levels 1..levels-1 from d_frame, plus a copy of level 0 into d_levels[0] */
     const uint8_t *d_frame;
@@ -153,7 +153,7 @@ typedef struct ofx_stream_stages {
 } ofx_stream_stages;
 int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
 /* Measurement hook: with a device buffer of 8 * capacity_blocks uint64 set, every wave of every later ofx_stream_launch
- * records its start and end time (100 MHz wall clock) at [2 * (4 * block + wave)]; first (9 ints, may be NULL) receives
+ * records its start and end time (100 MHz wall clock) at [2 * (4 * block + wave)]; first (2 * OFX_STREAM_MAX_BATCH + 1 ints, may be NULL) receives
  * the block ranges of the last launch (corner blocks first, then LK up to first[0], then the pyramid stages).
  * d_buf = NULL switches it off.  Process-global, not thread-safe. */
 int ofx_debug_stream_trace(unsigned long long *d_buf, int capacity_blocks, int *first);

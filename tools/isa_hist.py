@@ -29,11 +29,12 @@ heads = [i for i, l in enumerate(body) if "Loop Header" in l and "Depth=1" in l]
 best = None
 for h in heads:
     label = body[h].split(":")[0]
-    last = max((i for i, l in enumerate(body) if re.search(r"s_cbranch\w*\s+" + re.escape(label) + r"\b|s_branch\s+" + re.escape(label) + r"\b", l)), default=h)
-    # the loop's blocks may lie past its back edge: take everything tagged with this header
-    tag = "Header=" + label.lstrip(".L")
-    tagged = [i for i, l in enumerate(body) if tag in l]
-    last = max([last] + tagged)
+    # the loop's blocks are tagged "in Loop: Header=<label>"; it ends with the last of them (up to the next label)
+    tag = "Header=" + label.lstrip(".L") + " "
+    tagged = [i for i, l in enumerate(body) if tag in l + " "]
+    last = max([h] + tagged)
+    while last + 1 < len(body) and not body[last + 1].startswith(".LBB") and "s_endpgm" not in body[last + 1]:
+        last += 1
     seg = body[h:last + 1]
     n = sum("v_dot2c" in l for l in seg)
     if best is None or n > best[0]:

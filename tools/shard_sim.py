@@ -1,6 +1,6 @@
 """What one rank of an N-rank row-sharded run costs, measured on ONE GPU: a sharded local-corner session for rank r of N
 running the stream pipeline alone (ranks share nothing on the data path, so this is the per-rank time of the real run).
-    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4: frames per launch, default 4)"""
+    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4|8: frames per launch, default as bench.py: 4 for N = 1, else 8)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,10 +15,13 @@ frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1]).cuda() 
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 for N in worlds:
-    res = []
+    res, host = [], []
+    batch = int(os.environ.get("OFX_SIM_BATCH", "8" if N > 1 else "4"))
+    while batch * L > 40:  # OFX_MAX_LK_ITEMS
+        batch //= 2
     for r in sorted({0, N // 2, N - 1}):
         s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True,
-                           stream_batch=int(os.environ.get("OFX_SIM_BATCH", "4")))
+                           stream_batch=batch)
         s.stream_begin()
         t_ramp = time.perf_counter() + 0.2  # untimed: the first ~10 ms after start-up run 15-20 % slow (see bench.py)
         while time.perf_counter() < t_ramp:
@@ -29,8 +32,11 @@ for N in worlds:
         t0 = time.perf_counter()
         for i in range(steps):
             s.stream_submit(frames[i % 4])
+        t_host = time.perf_counter() - t0  # enqueue only: the host's share (it runs ahead of the GPU unless it is the limit)
         torch.cuda.synchronize()
         res.append((r, (time.perf_counter() - t0) / steps * 1e6))
+        host.append(t_host / steps * 1e6)
         s.close()
     worst = max(t for _, t in res)
-    print(f"{name} N={N}: " + "  ".join(f"rank {r}: {t:.1f} us" for r, t in res) + f"  -> {w * h / worst:.0f} Mpix/s if all ranks run like the slowest")
+    print(f"{name} N={N}: " + "  ".join(f"rank {r}: {t:.1f} us" for r, t in res) + f"  -> {w * h / worst:.0f} Mpix/s if all ranks run like the slowest"
+          f"  (host enqueue {max(host):.1f} us per frame)")

@@ -21,7 +21,8 @@ Lib.ofx_debug_stream_trace(buf.data_ptr(), cap, None)
 for i in range(B):
     s.stream_submit(frames[i % 4])
 torch.cuda.synchronize()
-first = (C.c_int * 9)()
+MAXB = 8  # OFX_STREAM_MAX_BATCH: blocks [0, MAXB) are the corner blocks, 2 * MAXB pyramid stages
+first = (C.c_int * (2 * MAXB + 1))()
 Lib.ofx_debug_stream_trace(None, 0, first)
 first = list(first)
 raw = buf.cpu().numpy().reshape(-1, 2)
@@ -37,23 +38,23 @@ def rng(a, b):
     m = ok[4 * a: 4 * b]
     x = us[4 * a: 4 * b][m]
     return x
-lk = rng(4, first[0])
-print(f"blocks: corner 0..3, LK 4..{first[0]}, pyramid stages {first}")
+lk = rng(MAXB, first[0])
+print(f"blocks: corner 0..{MAXB - 1}, LK {MAXB}..{first[0]}, pyramid stages {first}")
 print(f"LK waves {len(lk)}: start min/median/max {lk[:,0].min():.1f}/{np.median(lk[:,0]):.1f}/{lk[:,0].max():.1f} us, "
       f"end min/median/max {lk[:,1].min():.1f}/{np.median(lk[:,1]):.1f}/{lk[:,1].max():.1f} us, duration median {np.median(lk[:,1]-lk[:,0]):.1f}")
-for i in range(8):
+for i in range(2 * MAXB):
     if first[i + 1] > first[i]:
         p = rng(first[i], first[i + 1])
         print(f"pyramid stage {i}: {first[i+1]-first[i]} blocks, start min/median/max {p[:,0].min():.1f}/{np.median(p[:,0]):.1f}/{p[:,0].max():.1f}, "
               f"end max {p[:,1].max():.1f}, block duration median {np.median(p[:,1]-p[:,0]):.2f} p90 {np.percentile(p[:,1]-p[:,0],90):.2f} us")
-c = rng(0, 4)
+c = rng(0, MAXB)
 print(f"corner waves: {[(round(a,1), round(b,1)) for a, b in c if b > a]}")
 print(f"kernel span {us[ok,1].max():.1f} us")
 hist, edges = np.histogram(lk[:, 1], bins=12)
 print("LK end-time histogram:", [(round(e, 0), int(n)) for e, n in zip(edges[:-1], hist)])
 
 # where did the LK waves run?  HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh_id[12] se_id[15:13]
-sl = slice(4 * 4, 4 * first[0])
+sl = slice(4 * MAXB, 4 * first[0])
 m = ok[sl]
 simd = (hw[sl] >> 4) & 3; cu = (hw[sl] >> 8) & 0xf; sh = (hw[sl] >> 12) & 1; se = (hw[sl] >> 13) & 7
 key = (xcc[sl] * 8 + se) * 2 + sh
