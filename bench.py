@@ -75,8 +75,8 @@ def main():
     ap.add_argument("--borrow", action="store_true",
                     help="stream path: ofx_params.borrow_frames (no level-0 copy; the resident frames are read in place)")
     ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8],
-                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = 4 on one GPU, "
-                         "8 when a pair is sharded over several (a rank's share of a pair is small next to a launch's fixed cost)")
+                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = "
+                         "engine.suggest_stream_batch: by the footprint of a tick (4K: 4 on one GPU, 8 per rank of a sharded pair)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
                          "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
@@ -87,7 +87,11 @@ def main():
     # A stream tick carries `batch` frames and a step is one frame: the timed K steps (and the W warm-up steps before them)
     # must be whole ticks, or frames would be counted that were only queued.  Use the largest batch that divides both.
     if args.batch == 0:
-        args.batch = 8 if max(args.gpus, int(os.environ.get("WORLD_SIZE", "1"))) > 1 else 4
+        from cuda_optical_flow_2_amd.engine import suggest_stream_batch
+        from cuda_optical_flow_2_amd.parallel import ShardPlan
+        bw, bh, bl, bwin = WORKLOADS[args.workload]
+        n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
+        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None)
     while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch or
                               args.batch * WORKLOADS[args.workload][2] > 40):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2

@@ -41,6 +41,21 @@ class DeviceView:
         return torch.as_tensor(self, device="cuda")
 
 
+def suggest_stream_batch(width: int, height: int, levels: int, shard=None) -> int:
+    """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream: as many as the launch can carry
+    (OFX_MAX_LK_ITEMS = 40 (pair, level) items) while the flow fields of one tick stay under ~400 MB, but at least two.
+    Measured on MI355X: more frames per launch amortise the launch's fixed cost and the strips'
+    priming rows, until the tick's footprint (B flow fields at 8 B/px, written once each) starts to cost more than that
+    saves -- 4K: 2 / 4 / 8 frames per launch = 222k / 245k / 224k Mpix/s; 1080p: 4 / 8 = 205k / 226k; a rank of a sharded
+    pair holds 1/N of the rows and takes 8."""
+    rows = [(height >> k) if shard is None else (shard.own[k][1] - shard.own[k][0]) for k in range(levels)]
+    flow_bytes = 8 * sum((width >> k) * rows[k] for k in range(levels))
+    for b in (8, 4):
+        if b * levels <= 40 and b * flow_bytes <= 400e6:
+            return b
+    return 2
+
+
 class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 

@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_j
+O=$R/gpurun_out/prof_k
 rm -rf $O; mkdir -p $O
 cd $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -- python bench.py --no-cpu-baseline > $O/bench_stream.json 2> $O/stream.err

@@ -1,6 +1,6 @@
 """What one rank of an N-rank row-sharded run costs, measured on ONE GPU: a sharded local-corner session for rank r of N
 running the stream pipeline alone (ranks share nothing on the data path, so this is the per-rank time of the real run).
-    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4|8: frames per launch, default as bench.py: 4 for N = 1, else 8)"""
+    python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4|8: frames per launch, default engine.suggest_stream_batch, as bench.py)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,9 +16,7 @@ st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 for N in worlds:
     res, host = [], []
-    batch = int(os.environ.get("OFX_SIM_BATCH", "8" if N > 1 else "4"))
-    while batch * L > 40:  # OFX_MAX_LK_ITEMS
-        batch //= 2
+    batch = int(os.environ.get("OFX_SIM_BATCH", "0")) or engine.suggest_stream_batch(w, h, L, ShardPlan(w, h, L, win, 0, N) if N > 1 else None)
     for r in sorted({0, N // 2, N - 1}):
         s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True,
                            stream_batch=batch)
