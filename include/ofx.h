@@ -296,7 +296,7 @@ typedef struct ofx_params {
      * the patch; ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
-    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 = one launch per two / four frames
+    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 / 8 = one launch per that many frames
      * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
     /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame
@@ -346,7 +346,7 @@ int ofx_session_stage_shift(ofx_session *s, void *aux_stream);
 int ofx_session_solve_staged(ofx_session *s, void *stream);
 int ofx_session_aux_stream(ofx_session *s, void **stream);
 /* Stream pipeline (highest throughput): ONE launch (ofx_stream_launch) per tick of B = ofx_params.stream_batch frames
- * (1, 2 or 4), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
+ * (1, 2, 4 or 8), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
  * included) of the B pairs before that run side by side.  With B = 1 every call launches and the flow of pair p (frame
  * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  With B > 1 only every B-th call launches,
  * for the B frames received since the last launch (the others are remembered: their buffers must stay unmodified until
