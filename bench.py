@@ -365,6 +365,29 @@ def main():
                     "workload": "as value, but level 0 is read from the resident frames in place (no copy)",
                     "value": round(w * h / (ms3 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms3, 5), "steps": n3}
                 s3.close()
+            if args.path == "stream" and args.workload == "4k":
+                # the metric names 1080p pairs next to 4K ones (BASELINE.json): the same pipeline on the 1080p configuration
+                w5, h5, l5, win5 = WORKLOADS["1080p"]
+                b5 = engine.suggest_stream_batch(w5, h5, l5)
+                f5 = [torch.from_numpy(synth.smooth_pair(w5, h5, 2.0 * i * mx, 1.0 * i * my)[1]).cuda() for i in range(nframes)]
+                s5 = engine.Session(w5, h5, l5, win5, args.mode, device=local_rank, stream_batch=b5)
+                s5.stream_begin()
+                t_ramp = time.perf_counter() + 0.1
+                while time.perf_counter() < t_ramp:
+                    for i in range(64):
+                        s5.stream_submit(f5[i % nframes])
+                    torch.cuda.synchronize()
+                n5 = max(8 * b5, args.steps // b5 * b5)
+                t0 = time.perf_counter()
+                for i in range(n5):
+                    s5.stream_submit(f5[i % nframes])
+                torch.cuda.synchronize()
+                ms5 = (time.perf_counter() - t0) / n5 * 1e3
+                out["extra"]["workload_1080p"] = {
+                    "workload": f"{w5}x{h5} pair, {l5}-level pyramid, {win5}x{win5} window, iters=1, stream path, {b5} frames per launch",
+                    "value": round(w5 * h5 / (ms5 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms5, 5),
+                    "frames_per_s": round(1e3 / ms5, 1), "steps": n5}
+                s5.close()
         if dt_indep is not None:
             ms4 = dt_indep / args.steps * 1e3
             out.setdefault("extra", {})["independent_pairs_per_rank"] = {

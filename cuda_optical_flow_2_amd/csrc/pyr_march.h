@@ -133,8 +133,13 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
     const int y1_begin = r_start >> 1, y1_end = (Ye + 1) >> 1;
     load_row(2 * y1_begin, e_lo, e_hi);
     load_row(2 * y1_begin + 1, o_lo, o_hi);
-    for (int y1 = y1_begin; y1 < y1_end; ++y1) {
-        // fetch the next step's rows before touching this step's (consumed at the bottom of the loop)
+    // One step = level-1 row y1 (level-0 rows 2*y1, 2*y1 + 1).  PH = y1 mod 4 is a compile-time constant (the loop below is
+    // unrolled four times; r_start is a multiple of 2^n, so y1_begin is even when level 2 exists and a multiple of 4 when
+    // level 3 does): which of levels 2 and 3 a step feeds or completes is then static, and their state needs no
+    // conditional updates -- written with run-time tests on y1 the compiler merged the branches with ~55 v_mov per step.
+    auto step = [&](auto PHc, int y1) {
+        constexpr int PH = decltype(PHc)::value;
+        // fetch the next step's rows before touching this step's (consumed at the bottom of the step)
         uint32_t ne_lo, ne_hi, no_lo, no_hi;
         fetch_row(2 * y1 + 2, ne_lo, ne_hi);
         fetch_row(2 * y1 + 3, no_lo, no_hi);
@@ -144,55 +149,53 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
         // level 1, row y1: vertical [1 2 1] of rows 2y1-1, 2y1, 2y1+1 on the even / odd bytes, then horizontal
         uint32_t out1, out2 = 0, out3 = 0, out4 = 0, out5 = 0, out6 = 0; // outK: the level-K row this step completed (K <= n_out)
         int n_out = 1;
-        uint32_t v;
         {
             const uint32_t elo = (c_lo & M) + 2u * (e_lo & M) + (o_lo & M), olo = ((c_lo >> 8) & M) + 2u * ((e_lo >> 8) & M) + ((o_lo >> 8) & M);
             const uint32_t ehi = (c_hi & M) + 2u * (e_hi & M) + (o_hi & M), ohi = ((c_hi >> 8) & M) + 2u * ((e_hi >> 8) & M) + ((o_hi >> 8) & M);
             const uint32_t left = (uint32_t)lane_shift_right((int)ohi) >> 16; // the left lane's byte 7, summed
             const uint32_t a = 2u * elo + olo + ((olo << 16) | left);
             const uint32_t b = 2u * ehi + ohi + ((olo >> 16) | (ohi << 16));
-            v = (((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8) | (((b >> 4) & 0xffu) << 16) | (((b >> 20) & 0xffu) << 24)) & m1;
+            out1 = (((a >> 4) & 0xffu) | (((a >> 20) & 0xffu) << 8) | (((b >> 4) & 0xffu) << 16) | (((b >> 20) & 0xffu) << 24)) & m1;
             c_lo = o_lo;
             c_hi = o_hi;
         }
-        out1 = v;
         // deeper levels: level k gets a source row every 2^(k-2) steps, an even one waits in mid, an odd one completes a row
-        if (n >= 2) {
-            if ((y1 & 1) == 0) {
-                mid2 = out1;
-            } else {
+        if constexpr ((PH & 1) == 0) {
+            mid2 = out1;
+        } else {
+            if (n >= 2) {
                 out2 = level2(carry2, mid2, out1);
                 carry2 = out1;
                 n_out = 2;
+            }
+            if constexpr (PH == 1) {
+                mid3 = out2;
+            } else {
                 if (n >= 3) {
-                    if (((y1 >> 1) & 1) == 0) {
-                        mid3 = out2;
-                    } else {
-                        out3 = level3(carry3, mid3, out2);
-                        carry3 = out2;
-                        n_out = 3;
-                        if (n >= 4) {
-                            if (((y1 >> 2) & 1) == 0) {
-                                mid4 = out3;
-                            } else {
-                                out4 = level_n(4, carry4, mid4, out3);
-                                carry4 = out3;
-                                n_out = 4;
-                                if (n >= 5) {
-                                    if (((y1 >> 3) & 1) == 0) {
-                                        mid5 = out4;
-                                    } else {
-                                        out5 = level_n(5, carry5, mid5, out4);
-                                        carry5 = out4;
-                                        n_out = 5;
-                                        if (n >= 6) {
-                                            if (((y1 >> 4) & 1) == 0) {
-                                                mid6 = out5;
-                                            } else {
-                                                out6 = level_n(6, carry6, mid6, out5);
-                                                carry6 = out5;
-                                                n_out = 6;
-                                            }
+                    out3 = level3(carry3, mid3, out2);
+                    carry3 = out2;
+                    n_out = 3;
+                    if (n >= 4) {
+                        if (((y1 >> 2) & 1) == 0) {
+                            mid4 = out3;
+                        } else {
+                            out4 = level_n(4, carry4, mid4, out3);
+                            carry4 = out3;
+                            n_out = 4;
+                            if (n >= 5) {
+                                if (((y1 >> 3) & 1) == 0) {
+                                    mid5 = out4;
+                                } else {
+                                    out5 = level_n(5, carry5, mid5, out4);
+                                    carry5 = out4;
+                                    n_out = 5;
+                                    if (n >= 6) {
+                                        if (((y1 >> 4) & 1) == 0) {
+                                            mid6 = out5;
+                                        } else {
+                                            out6 = level_n(6, carry6, mid6, out5);
+                                            carry6 = out5;
+                                            n_out = 6;
                                         }
                                     }
                                 }
@@ -242,19 +245,29 @@ __device__ __forceinline__ void pyr_march_wave(const PyrMarchArgs &A, int item, 
                     if (mk[k]) gstore_u8(row, (uint32_t)xk[k], (uint8_t)value);
                 }
             };
-            store_level(2, out2);
-            store_level(3, out3);
-            store_level(4, out4);
-            store_level(5, out5);
-            store_level(6, out6);
+            if constexpr ((PH & 1) == 1) store_level(2, out2);
+            if constexpr (PH == 3) {
+                store_level(3, out3);
+                store_level(4, out4);
+                store_level(5, out5);
+                store_level(6, out6);
+            }
         }
         e_lo = ne_lo & m0lo;
         e_hi = ne_hi & m0hi;
         o_lo = no_lo & m0lo;
         o_hi = no_hi & m0hi;
-        // (keeps the masking on this side of the loop edge: sunk into the next step it would sit behind that step's loads,
+        // (keeps the masking on this side of the step's edge: sunk into the next step it would sit behind that step's loads,
         // and the wait in front of it would be a wait for those)
         asm volatile("" : "+v"(e_lo), "+v"(e_hi), "+v"(o_lo), "+v"(o_hi));
+    };
+    // Steps past y1_end (the last group of a strip) are harmless: rows outside the image read as zeros and every store is
+    // guarded by the strip's and the destination's row ranges.
+    for (int y1 = y1_begin; y1 < y1_end; y1 += 4) {
+        step(std::integral_constant<int, 0>{}, y1);
+        step(std::integral_constant<int, 1>{}, y1 + 1);
+        step(std::integral_constant<int, 2>{}, y1 + 2);
+        step(std::integral_constant<int, 3>{}, y1 + 3);
     }
 }
 
