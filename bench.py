@@ -72,11 +72,12 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--borrow", action="store_true",
-                    help="stream path: ofx_params.borrow_frames (no level-0 copy; the resident frames are read in place)")
+    ap.add_argument("--copy-frames", action="store_true",
+                    help="stream path: the session keeps its own copy of level 0 of every frame instead of reading the caller's ring "
+                         "of frames in place (ofx_params.borrow_frames = 0); the default run reports this variant under extra")
     ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = "
-                         "engine.suggest_stream_batch: by the footprint of a tick (4K: 4 on one GPU, 8 per rank of a sharded pair)")
+                         "engine.suggest_stream_batch: by the working set of the pipeline (4K: 4 on one GPU, 8 per rank of a sharded pair)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
                          "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
@@ -86,12 +87,13 @@ def main():
     args = ap.parse_args()
     # A stream tick carries `batch` frames and a step is one frame: the timed K steps (and the W warm-up steps before them)
     # must be whole ticks, or frames would be counted that were only queued.  Use the largest batch that divides both.
+    args.borrow = not args.copy_frames
     if args.batch == 0:
         from cuda_optical_flow_2_amd.engine import suggest_stream_batch
         from cuda_optical_flow_2_amd.parallel import ShardPlan
         bw, bh, bl, bwin = WORKLOADS[args.workload]
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
-        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None)
+        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow)
     while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch or
                               args.batch * WORKLOADS[args.workload][2] > 40):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2
@@ -138,6 +140,12 @@ def main():
     mx, my = (float(t) for t in os.environ.get("OFX_BENCH_MOTION", "1,1").split(","))
     frames = [synth.smooth_pair(w, h, 2.0 * i * mx, 1.0 * i * my)[1] for i in range(nframes)]
     d_frames = [torch.from_numpy(f).cuda() for f in frames]
+    # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
+    # hand them over: long enough for ofx_params.borrow_frames (a buffer stays untouched for 3 * batch further submits), and
+    # large enough that a frame is not still sitting in the 256 MB Infinity Cache when it comes round again (four buffers
+    # would be: with borrowed frames that alone made the LK stage ~10 % faster).  Contents repeat every four buffers.
+    ring_n = (3 * max(args.batch, 4) + 4 + 3) // 4 * 4
+    d_ring = [d_frames[i % nframes] if i < nframes else d_frames[i % nframes].clone() for i in range(ring_n)]
 
     if world == 1 and not force_dist:
         if args.iters > 1:
@@ -151,10 +159,10 @@ def main():
             # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
             sess.stream_begin()
             for i in range(12):
-                sess.stream_submit(d_frames[i % nframes])
+                sess.stream_submit(d_ring[i % ring_n])
 
             def step(i):
-                sess.stream_submit(d_frames[i % nframes])
+                sess.stream_submit(d_ring[i % ring_n])
         elif args.path == "staged":
             # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
             # pair's LK launch
@@ -177,15 +185,16 @@ def main():
         if args.shard_halo == "exchange":
             args.shard_corner = "broadcast"
         driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner,
-                                      stream_batch=args.batch, halo_mode=args.shard_halo)
+                                      stream_batch=args.batch, halo_mode=args.shard_halo,
+                                      borrow_frames=args.borrow and args.shard_corner == "local" and args.shard_halo != "exchange")
         sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
             for i in range(12):
-                driver.stream_submit(d_frames[i % nframes])
+                driver.stream_submit(d_ring[i % ring_n])
 
             def step(i):
-                driver.stream_submit(d_frames[i % nframes])
+                driver.stream_submit(d_ring[i % ring_n])
         else:
             driver.push_frame(d_frames[0])
 
@@ -233,18 +242,19 @@ def main():
     # Same step count, same fences, max over ranks.
     dt_indep = None
     if driver is not None:
-        # (four frames per launch as at N = 1: eight only pay when a launch carries a fraction of a pair)
-        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=min(args.batch, 4))
+        # (frames per launch as at N = 1: eight only pay when a launch carries a fraction of a pair)
+        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, borrow_frames=args.borrow,
+                            stream_batch=engine.suggest_stream_batch(w, h, levels, None, args.borrow))
         s4.stream_begin()
         t_ramp = time.perf_counter() + 0.1
         while time.perf_counter() < t_ramp:
             for i in range(64):
-                s4.stream_submit(d_frames[i % nframes])
+                s4.stream_submit(d_ring[i % ring_n])
             torch.cuda.synchronize()
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            s4.stream_submit(d_frames[i % nframes])
+            s4.stream_submit(d_ring[i % ring_n])
         fence()
         dt_indep = time.perf_counter() - t0
         s4.close()
@@ -304,6 +314,10 @@ def main():
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
+                "frames": (f"a ring of {ring_n} distinct device buffers, " +
+                           (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {3 * args.batch} further submits)"
+                            if args.borrow and ((driver is None and args.path == "stream") or (driver is not None and args.shard_corner == "local" and args.shard_halo != "exchange"))
+                            else "level 0 copied into the session")),
                 "sharding": "none" if driver is None else (
                     f"row blocks over {world} rank(s), halos recomputed from a wider level-0 halo; " +
                     ("every rank runs the one-launch stream pipeline on its block and forms the shift vectors from its own top-left "
@@ -347,22 +361,25 @@ def main():
                 "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms2, 5),
                 "frames_per_s": round(1e3 / ms2, 1), "steps": n2}}
             s2.close()
-            if args.path == "stream" and not args.borrow:
-                # the same stream path without its own copy of level 0 (ofx_params.borrow_frames: the caller keeps every frame
-                # unmodified for 3 * batch further submits -- true of this resident ring)
-                s3 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=args.batch, borrow_frames=True)
+            if args.path == "stream" and args.borrow:
+                # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
+                # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
+                b3 = engine.suggest_stream_batch(w, h, levels, None, False)
+                s3 = engine.Session(w, h, levels, window, args.mode, device=local_rank, stream_batch=b3, borrow_frames=False)
                 s3.stream_begin()
-                for i in range(12):
-                    s3.stream_submit(d_frames[i % nframes])
-                torch.cuda.synchronize()
-                n3 = max(40, min(args.steps, 200))
+                t_ramp = time.perf_counter() + 0.1
+                while time.perf_counter() < t_ramp:
+                    for i in range(64):
+                        s3.stream_submit(d_ring[i % ring_n])
+                    torch.cuda.synchronize()
+                n3 = max(8 * b3, args.steps // b3 * b3)
                 t0 = time.perf_counter()
                 for i in range(n3):
-                    s3.stream_submit(d_frames[i % nframes])
+                    s3.stream_submit(d_ring[i % ring_n])
                 torch.cuda.synchronize()
                 ms3 = (time.perf_counter() - t0) / n3 * 1e3
-                out["extra"]["stream_with_borrowed_frames"] = {
-                    "workload": "as value, but level 0 is read from the resident frames in place (no copy)",
+                out["extra"]["stream_with_copied_frames"] = {
+                    "workload": f"as value, but the session copies level 0 of every frame ({b3} frames per launch)",
                     "value": round(w * h / (ms3 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms3, 5), "steps": n3}
                 s3.close()
             if args.path == "stream" and args.workload == "4k":
@@ -370,17 +387,19 @@ def main():
                 w5, h5, l5, win5 = WORKLOADS["1080p"]
                 b5 = engine.suggest_stream_batch(w5, h5, l5)
                 f5 = [torch.from_numpy(synth.smooth_pair(w5, h5, 2.0 * i * mx, 1.0 * i * my)[1]).cuda() for i in range(nframes)]
+                r5 = (3 * b5 + 4 + 3) // 4 * 4
+                f5 = [f5[i % nframes] if i < nframes else f5[i % nframes].clone() for i in range(r5)]
                 s5 = engine.Session(w5, h5, l5, win5, args.mode, device=local_rank, stream_batch=b5)
                 s5.stream_begin()
                 t_ramp = time.perf_counter() + 0.1
                 while time.perf_counter() < t_ramp:
                     for i in range(64):
-                        s5.stream_submit(f5[i % nframes])
+                        s5.stream_submit(f5[i % r5])
                     torch.cuda.synchronize()
                 n5 = max(8 * b5, args.steps // b5 * b5)
                 t0 = time.perf_counter()
                 for i in range(n5):
-                    s5.stream_submit(f5[i % nframes])
+                    s5.stream_submit(f5[i % r5])
                 torch.cuda.synchronize()
                 ms5 = (time.perf_counter() - t0) / n5 * 1e3
                 out["extra"]["workload_1080p"] = {

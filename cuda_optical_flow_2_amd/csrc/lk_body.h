@@ -71,6 +71,11 @@ __device__ __forceinline__ uint32_t gload_u32(const uint8_t *base, uint32_t off)
 {
     return *(const OFX_GLOBAL uint32_t *)((const OFX_GLOBAL uint8_t *)base + lane_off(off));
 }
+// streaming read: data this launch (and the following ones) will not touch again
+__device__ __forceinline__ uint32_t gload_u32_nt(const uint8_t *base, uint32_t off)
+{
+    return __builtin_nontemporal_load((const OFX_GLOBAL uint32_t *)((const OFX_GLOBAL uint8_t *)base + lane_off(off)));
+}
 __device__ __forceinline__ uint32_t gload_u32_unaligned(const uint8_t *base, uint32_t off)
 {
     return ((const OFX_GLOBAL UnalignedU32 *)((const OFX_GLOBAL uint8_t *)base + lane_off(off)))->v;

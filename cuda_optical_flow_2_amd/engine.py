@@ -41,17 +41,20 @@ class DeviceView:
         return torch.as_tensor(self, device="cuda")
 
 
-def suggest_stream_batch(width: int, height: int, levels: int, shard=None) -> int:
-    """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream: as many as the launch can carry
-    (OFX_MAX_LK_ITEMS = 40 (pair, level) items) while the flow fields of one tick stay under ~400 MB, but at least two.
-    Measured on MI355X: more frames per launch amortise the launch's fixed cost and the strips'
-    priming rows, until the tick's footprint (B flow fields at 8 B/px, written once each) starts to cost more than that
-    saves -- 4K: 2 / 4 / 8 frames per launch = 222k / 245k / 224k Mpix/s; 1080p: 4 / 8 = 205k / 226k; a rank of a sharded
-    pair holds 1/N of the rows and takes 8."""
-    rows = [(height >> k) if shard is None else (shard.own[k][1] - shard.own[k][0]) for k in range(levels)]
-    flow_bytes = 8 * sum((width >> k) * rows[k] for k in range(levels))
+def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borrow_frames: bool = False) -> int:
+    """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream on MI355X: the largest B in {8, 4} the launch
+    can carry (OFX_MAX_LK_ITEMS = 40 (pair, level) items) whose cyclic working set stays inside the 256 MB Infinity Cache,
+    else 2.  The working set is what lives between a frame's arrival and its last use: the session's 3B+2 image sets (the
+    whole pyramid, or levels >= 1 only with borrow_frames) plus the caller's ring of frames (at least 3B+4 buffers with
+    borrow_frames, assumed four deeper than a tick otherwise).  Measured: the fused level kernel
+    runs ~25 % slower when its image rows come from HBM instead of that cache -- 4K, copied frames: 2 / 4 frames per launch
+    = 222k / 197k Mpix/s; borrowed frames: 4 / 8 = 251k / 219k; 1080p and the ranks of a sharded pair take 8."""
+    rows = [(height >> k) if shard is None else (shard.buf[k][1] - shard.buf[k][0]) for k in range(levels)]
+    level_bytes = [(width >> k) * rows[k] for k in range(levels)]
     for b in (8, 4):
-        if b * levels <= 40 and b * flow_bytes <= 400e6:
+        ring = (3 * max(b, 4) + 4 + 3) // 4 * 4
+        working_set = (3 * b + 2) * sum(level_bytes[1 if borrow_frames else 0:]) + ring * level_bytes[0]
+        if b * levels <= 40 and working_set <= 230e6:
             return b
     return 2
 

@@ -101,12 +101,13 @@ class HipBackend:
     """The device-resident session of libofx_hip.so behind the operations ShardedFlow needs."""
 
     def __init__(self, plan: ShardPlan, mode: str, device: int, local_corner: bool = False, patch_size: int = 0,
-                 stream_batch: int = 1):
+                 stream_batch: int = 1, borrow_frames: bool = False):
         from . import engine
 
         self.plan = plan
         self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan,
-                                      local_corner=local_corner, patch_size=patch_size, stream_batch=stream_batch)
+                                      local_corner=local_corner, patch_size=patch_size, stream_batch=stream_batch,
+                                      borrow_frames=borrow_frames)
         self._views = {}
         # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
         self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
@@ -176,13 +177,13 @@ class ShardedFlow:
     """One frame pair per step(), row-sharded over the ranks of the default process group."""
 
     def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True,
-                 corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute"):
+                 corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute", borrow_frames=False):
         assert corner in ("broadcast", "local")
         assert halo_mode == "recompute" or corner == "broadcast", "the exchange mode is pair-at-a-time (rank 0's corner + broadcast)"
         self.plan = ShardPlan(width, height, levels, window, rank, world, margin, halo_mode)
         self.rank, self.world, self.pipelined, self.corner = rank, world, pipelined, corner
         self.backend = backend if backend is not None else HipBackend(self.plan, mode, device, corner == "local", patch_size,
-                                                                      stream_batch)
+                                                                      stream_batch, borrow_frames)
         self.session = getattr(self.backend, "session", None)
 
     # ---- stream pipeline (corner == "local", HIP sessions): one launch per frame on every rank, nothing between ranks

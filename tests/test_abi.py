@@ -81,13 +81,14 @@ def test_product_does_not_import_oracle():
 
 
 def test_suggested_frames_per_launch():
-    """Host logic of engine.suggest_stream_batch: bounded by OFX_MAX_LK_ITEMS and by the footprint of a tick."""
+    """Host logic of engine.suggest_stream_batch: bounded by OFX_MAX_LK_ITEMS and by the pipeline's working set."""
     from cuda_optical_flow_2_amd.engine import suggest_stream_batch
     from cuda_optical_flow_2_amd.parallel import ShardPlan
 
-    assert suggest_stream_batch(3840, 2160, 5, None) == 4      # 8 x 88 MB of flow per tick is past the knee (measured)
+    assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=True) == 4   # the measured optima (DESIGN.md section 4.3)
+    assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=False) == 2
     assert suggest_stream_batch(1920, 1080, 4, None) == 8
     assert suggest_stream_batch(7680, 4320, 6, None) == 2      # never below two frames per launch
-    assert suggest_stream_batch(3840, 2160, 5, ShardPlan(3840, 2160, 5, 9, 3, 8)) == 8
+    assert suggest_stream_batch(3840, 2160, 5, ShardPlan(3840, 2160, 5, 9, 3, 8), True) == 8
     for w, h, L in [(640, 480, 7), (7680, 4320, 6), (64, 64, 2)]:
         assert suggest_stream_batch(w, h, L, None) * L <= 40   # OFX_MAX_LK_ITEMS

@@ -9,7 +9,8 @@ cfg = {"4k": (3840, 2160, 5, 9), "1080p": (1920, 1080, 4, 7), "8k": (7680, 4320,
 path = sys.argv[2] if len(sys.argv) > 2 else "plain"
 w, h, L, win = cfg
 p, n = synth.smooth_pair(w, h)
-s = engine.Session(w, h, L, win, "lk_float", stream_batch=4 if path == "stream" else 1)  # as bench.py runs it
+B = engine.suggest_stream_batch(w, h, L, None, True)  # as bench.py runs it: borrowed frames from a ring of distinct buffers
+s = engine.Session(w, h, L, win, "lk_float", stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream")
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     if path == "plain":
@@ -18,9 +19,10 @@ with torch.cuda.stream(st):
         for i in range(6):
             s.run_flow()
     else:
-        frames = [torch.from_numpy(x).cuda() for x in (p, n)]
+        ring = (3 * max(B, 4) + 4 + 3) // 4 * 4
+        frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * (i % 4), 1.0 * (i % 4))[1]).cuda() for i in range(ring)]
         s.stream_begin()
-        for i in range(40):
-            s.stream_submit(frames[i & 1])
+        for i in range(10 * B):
+            s.stream_submit(frames[i % ring])
 torch.cuda.synchronize()
 s.close()

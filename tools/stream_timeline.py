@@ -8,18 +8,21 @@ from cuda_optical_flow_2_amd import engine, lib, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 w, h, L, win = 3840, 2160, 5, 9
 frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1]).cuda() for i in range(4)]
+RING = int(os.environ.get("OFX_TL_RING", str((3 * max(B, 4) + 4 + 3) // 4 * 4)))  # distinct source buffers, as bench.py
+frames = [frames[i % 4] if i < 4 else frames[i % 4].clone() for i in range(RING)]
+BORROW = os.environ.get("OFX_TL_BORROW", "1") == "1"  # as bench.py
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
-s = engine.Session(w, h, L, win, "lk_float", stream_batch=B)
+s = engine.Session(w, h, L, win, "lk_float", stream_batch=B, borrow_frames=BORROW)
 s.stream_begin()
 for i in range(10 * B):
-    s.stream_submit(frames[i % 4])
+    s.stream_submit(frames[i % RING])
 torch.cuda.synchronize()
 cap = 16384
 buf = torch.zeros(8 * cap, dtype=torch.int64, device="cuda")
 Lib = lib.load()
 Lib.ofx_debug_stream_trace(buf.data_ptr(), cap, None)
 for i in range(B):
-    s.stream_submit(frames[i % 4])
+    s.stream_submit(frames[(10 * B + i) % RING])
 torch.cuda.synchronize()
 MAXB = 8  # OFX_STREAM_MAX_BATCH: blocks [0, MAXB) are the corner blocks, 2 * MAXB pyramid stages
 first = (C.c_int * (2 * MAXB + 1))()
