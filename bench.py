@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--iters", type=int, default=1,
                     help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the additional legs reported under extra (profiling runs: only the timed configuration's launches)")
     ap.add_argument("--copy-frames", action="store_true",
                     help="stream path: the session keeps its own copy of level 0 of every frame instead of reading the caller's ring "
                          "of frames in place (ofx_params.borrow_frames = 0); the default run reports this variant under extra")
@@ -339,7 +341,7 @@ def main():
                 "traffic": traffic,
             },
         }
-        if world == 1 and not force_dist and args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS:
+        if world == 1 and not force_dist and not args.no_extras and args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS:
             # BASELINE.json's configs carry "N iters"; the reference has no iterations, so they run as the
             # lk_iter extension here, next to the reference-defined line above (same process, same frames, plain path)
             it = BASELINE_ITERS[args.workload]

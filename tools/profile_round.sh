@@ -1,11 +1,11 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_k
+O=$R/gpurun_out/prof_l
 rm -rf $O; mkdir -p $O
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -- python bench.py --no-cpu-baseline > $O/bench_stream.json 2> $O/stream.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/plain -- python bench.py --no-cpu-baseline --path plain > $O/bench_plain.json 2> $O/plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -- python bench.py --no-cpu-baseline --no-extras > $O/bench_stream.json 2> $O/stream.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/plain -- python bench.py --no-cpu-baseline --no-extras --path plain > $O/bench_plain.json 2> $O/plain.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_stream -- python tools/pmc_run.py 4k stream > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_stream -- python tools/pmc_run.py 4k stream > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_plain -- python tools/pmc_run.py 4k plain > /dev/null 2>&1

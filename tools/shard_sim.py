@@ -17,7 +17,7 @@ st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 for N in worlds:
     res, host = [], []
-    batch = int(os.environ.get("OFX_SIM_BATCH", "0")) or engine.suggest_stream_batch(w, h, L, ShardPlan(w, h, L, win, 0, N) if N > 1 else None)
+    batch = int(os.environ.get("OFX_SIM_BATCH", "0")) or engine.suggest_stream_batch(w, h, L, ShardPlan(w, h, L, win, 0, N) if N > 1 else None, BORROW)
     ring = (3 * max(batch, 4) + 4 + 3) // 4 * 4
     while len(frames) < ring:
         frames.append(frames[len(frames) % 4].clone())
