@@ -174,6 +174,44 @@ def test_pair_vs_oracle(eng, oracle, cfg, mode):
         assert_same(got[k], want[k], f"{mode} L{k}")
 
 
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, "lk_float"), (320, 700, 2, 15, "lk_float"), (252, 400, 3, 5, "compat_cpu")])
+def test_tall_strips_refresh_the_row_map(eng, oracle, cfg, monkeypatch):
+    """The march keeps the reference's row map (int)((float)y + v) for 64 rows at a time in a lane table and refreshes it
+    when the entering row runs off its end (lk_body.h).  Small frames are normally cut into 8-row strips, which never get
+    there: OFX_LK_MIN_STRIP forces strips as tall as the level, so every wave refreshes several times -- plain launch and
+    stream kernel against the oracle."""
+    w, h, levels, win, mode = cfg
+    monkeypatch.setenv("OFX_LK_MIN_STRIP", "1000")
+    frames = [synth.smooth_pair(w, h, 1.7 * i, -2.3 * i, seed=11)[1] for i in range(5)]
+    want = [oracle.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), levels, win, mode, exact_sums=True)[0] for i in range(1, 5)]
+    for i in range(1, 5):
+        got = eng.flow_pair(frames[i - 1], frames[i], levels, win, mode)
+        for k in range(levels):
+            assert_same(got[k], want[i - 1][k], f"plain pair {i} L{k}")
+    import torch
+
+    s = eng.Session(w, h, levels, win, mode, stream_batch=2)
+    s.stream_begin()
+    d = [torch.from_numpy(f).cuda() for f in frames]
+    seen = {}
+    def snap(done):
+        for p in (done - 1, done):
+            if p >= 1 and p not in seen:
+                seen[p] = [s.flow_of(p, k)[0].cpu().numpy() for k in range(levels)]
+    for f in d:
+        snap(s.stream_submit(f))
+    while True:
+        done = s.stream_drain()
+        if done == -2:
+            break
+        snap(done)
+    s.close()
+    assert sorted(seen) == [1, 2, 3, 4]
+    for p in seen:
+        for k in range(levels):
+            assert_same(seen[p][k], want[p - 1][k], f"stream pair {p} L{k}")
+
+
 def test_session_planes_and_streaming(eng, oracle):
     """Pyramid planes equal the oracle's, and prev/next swap keeps the previous pyramid (main.cu:270-272)."""
     import torch
