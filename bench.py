@@ -148,6 +148,18 @@ def main():
     # would be: with borrowed frames that alone made the LK stage ~10 % faster).  Contents repeat every four buffers.
     ring_n = (3 * max(args.batch, 4) + 4 + 3) // 4 * 4
     d_ring = [d_frames[i % nframes] if i < nframes else d_frames[i % nframes].clone() for i in range(ring_n)]
+    # the frames of one tick go down in one call (ofx_session_stream_submit_frames): step i of a tick only counts, the tick's
+    # last step submits -- the per-frame FFI crossing is what limits small frames and the ranks of a sharded pair.
+    # (tick j takes ring buffers j*B .. j*B + B - 1 modulo the ring; the sequence of ticks repeats after lcm(ring, B) frames)
+    import math
+    d_groups = [engine.FrameGroup([d_ring[(j * args.batch + k) % ring_n] for k in range(args.batch)])
+                for j in range(math.lcm(ring_n, args.batch) // args.batch)]
+
+    def stream_step_fn(submit_frames):
+        def step(i):
+            if i % args.batch == args.batch - 1:
+                submit_frames(d_groups[(i // args.batch) % len(d_groups)])
+        return step
 
     if world == 1 and not force_dist:
         if args.iters > 1:
@@ -160,11 +172,9 @@ def main():
             # one launch per frame: pyramid(frame j) | corner(pair j-1) | fused LK(pair j-2, global shift in its loads) side by side in
             # one grid (ofx_session_stream_submit); every step completes exactly one pair once the pipeline is full
             sess.stream_begin()
-            for i in range(12):
-                sess.stream_submit(d_ring[i % ring_n])
-
-            def step(i):
-                sess.stream_submit(d_ring[i % ring_n])
+            step = stream_step_fn(sess.stream_submit_frames)
+            for i in range(3 * args.batch):
+                step(i)
         elif args.path == "staged":
             # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
             # pair's LK launch
@@ -192,11 +202,9 @@ def main():
         sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
-            for i in range(12):
-                driver.stream_submit(d_ring[i % ring_n])
-
-            def step(i):
-                driver.stream_submit(d_ring[i % ring_n])
+            step = stream_step_fn(driver.stream_submit_frames)
+            for i in range(3 * args.batch):
+                step(i)
         else:
             driver.push_frame(d_frames[0])
 

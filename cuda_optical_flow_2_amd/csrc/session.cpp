@@ -806,6 +806,20 @@ extern "C" int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1,
     return stream_tick(s, fr, pt, n, stream, completed_pair);
 }
 
+extern "C" int ofx_session_stream_submit_frames(ofx_session *s, const uint8_t *const *d_gray1, const int *pitches, int pitch0, int n,
+                                                void *stream, int *completed_pair)
+{
+    OFX_REQUIRE(s && d_gray1 && n >= 1, "ofx_session_stream_submit_frames: bad arguments");
+    int newest = -1;
+    for (int i = 0; i < n; ++i) {
+        int done = -1;
+        OFX_TRY(ofx_session_stream_submit(s, d_gray1[i], pitches ? pitches[i] : pitch0, stream, &done));
+        newest = done > newest ? done : newest;
+    }
+    if (completed_pair) *completed_pair = newest;
+    return OFX_OK;
+}
+
 // Run one more tick without a new frame (frames still waiting for their tick to fill go out with it); call until it
 // reports -2 in *completed_pair (pipeline empty).  Two ticks drain a full pipeline.
 extern "C" int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair)

@@ -41,6 +41,17 @@ class DeviceView:
         return torch.as_tensor(self, device="cuda")
 
 
+class FrameGroup:
+    """Consecutive frames of a stream as one argument block for Session.stream_submit_frames (keeps the tensors alive)."""
+
+    def __init__(self, tensors):
+        self.tensors = list(tensors)
+        self.n = len(self.tensors)
+        assert self.n >= 1 and all(t.is_cuda and t.dtype.itemsize == 1 and t.stride(0) == self.tensors[0].stride(0) for t in self.tensors)
+        self.pitch = int(self.tensors[0].stride(0))
+        self.ptrs = (_vp * self.n)(*[t.data_ptr() for t in self.tensors])
+
+
 def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borrow_frames: bool = False) -> int:
     """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream on MI355X: the largest B in {8, 4} the launch
     can carry (OFX_MAX_LK_ITEMS = 40 (pair, level) items) whose cyclic working set stays inside the 256 MB Infinity Cache,
@@ -175,6 +186,16 @@ class Session:
         done = C.c_int(-1)
         check(self.L.ofx_session_stream_submit(self._h, t.data_ptr(), int(t.stride(0)), _stream_ptr(stream), C.byref(done)),
               "stream_submit")
+        return done.value
+
+    def stream_submit_frames(self, frames, stream=None) -> int:
+        """Several consecutive frames in one call (ofx_session_stream_submit_frames): one FFI crossing per group instead of
+        one per frame.  `frames`: a sequence of device tensors of equal pitch, or a FrameGroup packed once for a ring that is
+        reused.  Returns the highest pair complete after the call, or -1."""
+        g = frames if isinstance(frames, FrameGroup) else FrameGroup(frames)
+        done = C.c_int(-1)
+        check(self.L.ofx_session_stream_submit_frames(self._h, g.ptrs, None, g.pitch, g.n, _stream_ptr(stream), C.byref(done)),
+              "stream_submit_frames")
         return done.value
 
     def stream_drain(self, stream=None) -> int:

@@ -92,6 +92,7 @@ _SIGS = {
     "ofx_session_flow_of": [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "ofx_session_stream_submit": [_vp, _vp, _i, _vp, C.POINTER(_i)],
     "ofx_session_stream_drain": [_vp, _vp, C.POINTER(_i)],
+    "ofx_session_stream_submit_frames": [_vp, C.POINTER(_vp), C.POINTER(_i), _i, _i, _vp, C.POINTER(_i)],
     "ofx_stream_launch": [_vp, _i, _i, _vp],
     "ofx_session_submit_device": [_vp, _vp, _i, _vp],
     "ofx_session_stage_frame": [_vp, _vp, _i, _vp],

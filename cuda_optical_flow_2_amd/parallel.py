@@ -195,6 +195,10 @@ class ShardedFlow:
         """Next frame of the stream; returns the pair whose flow (this rank's rows) the launch writes, or -1."""
         return self.session.stream_submit(frame)
 
+    def stream_submit_frames(self, frames) -> int:
+        """Several consecutive frames in one call (engine.FrameGroup or a sequence of device tensors)."""
+        return self.session.stream_submit_frames(frames)
+
     def stream_drain(self) -> int:
         return self.session.stream_drain()
 

@@ -358,6 +358,11 @@ int ofx_session_aux_stream(ofx_session *s, void **stream);
 int ofx_session_stream_begin(ofx_session *s);
 int ofx_session_stream_submit(ofx_session *s, const uint8_t *d_gray1, int pitch, void *stream, int *completed_pair);
 int ofx_session_stream_drain(ofx_session *s, void *stream, int *completed_pair);
+/* The same for n consecutive frames in one call (n >= 1; pitches may be NULL when every frame's pitch is `pitch0`): exactly
+ * what n calls of ofx_session_stream_submit do, for callers whose frames arrive in groups or whose call overhead counts
+ * (an FFI call per frame is ~1.5 us; a rank of an 8-way sharded 4K pair spends ~5 us of GPU time per frame). */
+int ofx_session_stream_submit_frames(ofx_session *s, const uint8_t *const *d_gray1, const int *pitches, int pitch0, int n, void *stream,
+                                     int *completed_pair);
 /* Flow of `pair` at `level` while it is one of the newest stream_batch completed pairs of the stream pipeline (pair p
  * lives in flow set p mod stream_batch).  Same outputs as ofx_session_flow. */
 int ofx_session_flow_of(ofx_session *s, int pair, int level, float **d_ptr, int *row0, int *rows);

@@ -212,6 +212,50 @@ def test_tall_strips_refresh_the_row_map(eng, oracle, cfg, monkeypatch):
             assert_same(seen[p][k], want[p - 1][k], f"stream pair {p} L{k}")
 
 
+def test_stream_submit_frames_equals_single_submits(eng):
+    """ofx_session_stream_submit_frames(n frames) == n calls of ofx_session_stream_submit: same pairs reported, same bits;
+    group sizes that do and do not line up with the frames per launch."""
+    import torch
+
+    w, h, L, win = 320, 240, 3, 7
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.5 * i, 0.5 * i, seed=3)[1]).cuda() for i in range(13)]
+
+    def run(group_sizes, batch):
+        s = eng.Session(w, h, L, win, "lk_float", stream_batch=batch)
+        s.stream_begin()
+        out, seen, i = {}, 0, 0
+        def snap(done):
+            nonlocal seen
+            for p in range(max(seen + 1, done - batch + 1), done + 1):
+                out[p] = [s.flow_of(p, k)[0].cpu().numpy() for k in range(L)]
+            seen = max(seen, done)
+        for g in group_sizes:
+            done = s.stream_submit_frames(frames[i:i + g]) if g > 1 else s.stream_submit(frames[i])
+            i += g
+            if done >= 1:
+                snap(done)
+        assert i == len(frames)
+        while True:
+            done = s.stream_drain()
+            if done == -2:
+                break
+            if done >= 1:
+                snap(done)
+        s.close()
+        return out
+
+    for batch in (1, 4):
+        ref = run([1] * 13, batch)
+        assert sorted(ref) == list(range(1, 13))
+        for sizes in ([4, 4, 4, 1], [3, 5, 2, 3], [13]):
+            got = run(sizes, batch)
+            # a group larger than a tick completes several ticks in one call: only the newest `batch` pairs are still readable
+            assert set(got) <= set(ref) and max(got) == 12
+            for p in got:
+                for k in range(L):
+                    assert_same(got[p][k], ref[p][k], f"batch {batch} groups {sizes} pair {p} L{k}")
+
+
 def test_session_planes_and_streaming(eng, oracle):
     """Pyramid planes equal the oracle's, and prev/next swap keeps the previous pyramid (main.cu:270-272)."""
     import torch

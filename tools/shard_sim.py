@@ -1,7 +1,7 @@
 """What one rank of an N-rank row-sharded run costs, measured on ONE GPU: a sharded local-corner session for rank r of N
 running the stream pipeline alone (ranks share nothing on the data path, so this is the per-rank time of the real run).
     python tools/shard_sim.py [workload] [N ...]      (OFX_SIM_BATCH=1|2|4|8: frames per launch, default engine.suggest_stream_batch, as bench.py)"""
-import os, sys, time
+import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cuda_optical_flow_2_amd import engine, synth
@@ -21,19 +21,21 @@ for N in worlds:
     ring = (3 * max(batch, 4) + 4 + 3) // 4 * 4
     while len(frames) < ring:
         frames.append(frames[len(frames) % 4].clone())
+    # a tick's frames go down in one call, as in bench.py (tick j takes ring buffers j*B .. j*B + B - 1 modulo the ring)
+    groups = [engine.FrameGroup([frames[(j * batch + k) % ring] for k in range(batch)]) for j in range(math.lcm(ring, batch) // batch)]
     for r in sorted({0, N // 2, N - 1}):
         s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True,
                            stream_batch=batch, borrow_frames=BORROW)
         s.stream_begin()
         t_ramp = time.perf_counter() + 0.2  # untimed: the first ~10 ms after start-up run 15-20 % slow (see bench.py)
         while time.perf_counter() < t_ramp:
-            for i in range(64):
-                s.stream_submit(frames[i % ring])
+            for i in range(64 // batch):
+                s.stream_submit_frames(groups[i % len(groups)])
             torch.cuda.synchronize()
         steps = 2000
         t0 = time.perf_counter()
-        for i in range(steps):
-            s.stream_submit(frames[i % ring])
+        for i in range(steps // batch):
+            s.stream_submit_frames(groups[i % len(groups)])
         t_host = time.perf_counter() - t0  # enqueue only: the host's share (it runs ahead of the GPU unless it is the limit)
         torch.cuda.synchronize()
         res.append((r, (time.perf_counter() - t0) / steps * 1e6))
