@@ -24,7 +24,7 @@ __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
 } // namespace
 
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
-                    CornerArgs *out)
+                    const int *shard_rows, CornerArgs *out)
 {
     OFX_REQUIRE(levels && d_uv && n_levels >= 1 && n_levels <= OFX_MAX_LEVELS, "ofx_corner_flows: bad arguments");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_corner_flows: window must be odd and >= 3 (got %d)", window);
@@ -47,7 +47,9 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
         const int col_end = cols && cols[k] > 0 ? cols[k] : g->w;
         OFX_REQUIRE(col_end <= g->pitch && col_end >= (a.radius + 2 < g->w ? a.radius + 2 : g->w),
                     "ofx_corner_flows: level %d holds %d columns, the corner needs %d", k, col_end, a.radius + 2);
-        a.lv[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0, col_end};
+        a.lv[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0, col_end,
+                                shard_rows ? shard_rows[4 * k] : 0, shard_rows ? shard_rows[4 * k + 1] : 0, shard_rows ? shard_rows[4 * k + 2] : 0,
+                                shard_rows ? shard_rows[4 * k + 3] : 0};
     }
     *out = a;
     return OFX_OK;
@@ -56,7 +58,7 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
 extern "C" int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, void *stream)
 {
     CornerArgs a{};
-    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, &a));
+    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, nullptr, &a));
     if (mode == OFX_MODE_LK_FLOAT)
         hipLaunchKernelGGL(corner_kernel<OFX_MODE_LK_FLOAT>, dim3(1), dim3(64), 0, ofx_stream(stream), a);
     else

@@ -12,12 +12,16 @@ struct CornerLevel {
     float *flow;         // pixel 0 is written when flow_row0 == 0
     int w, h, pitch, row_end, flow_row0;
     int col_end; // the planes hold columns [0, col_end) and rows [0, row_end) of the w x h level (a top-left patch, or all of it)
+    // row-sharded sessions (all zero: unchecked): the image rows [need0, need1) the level kernel's stencils of this shard
+    // touch before the shift, and the rows [valid0, valid1) its buffers hold
+    int need0, need1, valid0, valid1;
 };
 
 struct CornerArgs {
     CornerLevel lv[OFX_MAX_LEVELS];
     float *uv;   // 2 floats per level
-    int *status; // optional: bit k is set when level k needed a pixel inside the image but outside its planes
+    int *status; // optional: bit k is set when level k needed a pixel inside the image but outside its planes, bit 8 + k
+                 // when level k's vertical shift sends the shard's reads to image rows its buffers do not hold
     int levels, radius;
 };
 
@@ -137,6 +141,15 @@ __device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float
         if (shifted && lane == 0) {
             A.uv[2 * k] = u;
             A.uv[2 * k + 1] = v;
+            // a row-sharded level kernel reads next at row (int)(y + v) for the rows y its stencils touch: targets inside the
+            // image must be rows the shard holds (targets outside the image read nothing; a NaN shift moves nothing)
+            if (A.status != nullptr && L.need1 > L.need0 && v == v) {
+                const float t0 = (float)L.need0 + v, t1 = (float)(L.need1 - 1) + v; // the map is monotone: its two ends decide
+                if (t1 > -1.0f && t0 < (float)L.h) {
+                    const int lo = max(0, (int)floorf(t0)), hi = min(L.h - 1, (int)floorf(t1));
+                    if (lo <= hi && (lo < L.valid0 || hi >= L.valid1)) atomicOr(A.status, 1 << (8 + k));
+                }
+            }
         }
         // Stage 1: every pixel the window's 3x3 stencils can touch -- x, y in [-1, radius+1] -- is resolved ONCE (border
         // rule, shift, patch extents) into two small LDS tiles, prev and shifted next, indexed by coordinate + 1.  A lone wave

@@ -356,7 +356,7 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     for (int i = 0; i < g->n_corner; ++i) {
         const ofx_corner_stage &C = g->corner[i];
         OFX_REQUIRE(C.levels > 0, "ofx_stream_launch: empty corner stage");
-        OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &S.corner[i]));
+        OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &C.shard_rows[0][0], &S.corner[i]));
     }
     S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LK_ITEMS];

@@ -60,6 +60,7 @@ int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, ui
                            uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, int target_waves,
                            ofx_dev::PyrMarchArgs *out, int *items);
 int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *out, int *blocks_out);
-// cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerArgs::status
+// cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerArgs::status;
+// shard_rows (NULL: unchecked): 4 ints per level, CornerLevel::need0 .. valid1
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
-                    ofx_dev::CornerArgs *out);
+                    const int *shard_rows, ofx_dev::CornerArgs *out);

@@ -725,7 +725,18 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                 C.level[k] = ofx_lk_desc{plane_of(pc - 1, k), plane_of(pc, k), cg, nullptr, 0, nullptr, 0};
             }
         }
-        if (s->p.local_corner) C.d_status = s->corner_status;
+        if (s->p.local_corner) {
+            C.d_status = s->corner_status;
+            if (s->p.sharded)
+                for (int k = 0; k < L; ++k) {
+                    const int reach = s->p.window / 2 + 1; // the LK stencil of the own rows reaches radius + 1 rows beyond them
+                    const int n0 = s->own0[k] - reach, n1 = s->own1[k] + reach;
+                    C.shard_rows[k][0] = n0 < 0 ? 0 : n0;
+                    C.shard_rows[k][1] = n1 > s->h[k] ? s->h[k] : n1;
+                    C.shard_rows[k][2] = s->cmp0[k];
+                    C.shard_rows[k][3] = s->cmp1[k];
+                }
+        }
     }
     long newest = -1;
     for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote

@@ -136,12 +136,16 @@ typedef struct ofx_corner_stage {
     /* descriptors as for ofx_corner_flows.  cols[k] > 0: the planes of level k are a patch holding columns [0, cols[k])
      * and rows [0, geom.rows) of the geom.w x geom.h level; d_status (may be NULL): bit k is OR-ed in when level k needed
      * a pixel inside the image but outside its planes (the shift left the patch: that pair's result is not the
-     * reference's). */
+     * reference's).  shard_rows[k] = {need0, need1, valid0, valid1} (all zero: unchecked), for a row-sharded caller: the
+     * image rows [need0, need1) of level k that the LK stencils of this shard touch and the rows [valid0, valid1) its
+     * buffers hold; bit 8 + k is OR-ed in when level k's vertical shift sends those reads to rows that exist in the image
+     * but not in the shard (the rows of that pair next to the shard's edge are then not the reference's). */
     ofx_lk_desc level[OFX_MAX_LEVELS];
     int levels;
     float *d_uv;
     int cols[OFX_MAX_LEVELS];
     int *d_status;
+    int shard_rows[OFX_MAX_LEVELS][4];
 } ofx_corner_stage;
 typedef struct ofx_stream_stages {
     ofx_pyramid_stage pyr[OFX_STREAM_MAX_BATCH];
@@ -310,8 +314,9 @@ typedef struct ofx_params {
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
-/* local_corner sessions: *h_status receives (and the session clears) the OR over all pairs so far of "level k's shift
- * left the patch" bits; 0 = every corner flow was computed from pixels the patch holds.  Synchronises `stream`. */
+/* local_corner sessions: *h_status receives (and the session clears) the OR over all pairs so far of bit k = "level k's
+ * shift left the patch" and bit 8 + k = "level k's vertical shift reached image rows beyond this shard's halo" (the margin
+ * rows of the plan); 0 = every pair so far is exactly the unsharded result.  Synchronises `stream`. */
 int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream);
 int ofx_session_destroy(ofx_session *s);
 /* Load the NEXT frame's level 0 (1ch, tightly packed w bytes per row, full frame) from host / device memory. */

@@ -212,6 +212,37 @@ def test_tall_strips_refresh_the_row_map(eng, oracle, cfg, monkeypatch):
             assert_same(seen[p][k], want[p - 1][k], f"stream pair {p} L{k}")
 
 
+def test_sharded_session_reports_a_shift_beyond_its_halo(eng):
+    """A rank's buffers hold `margin` rows of slack for the reference's global shift.  A pair whose pixel-0 flow is wild
+    (found by tools/fuzz_stream.py: a degenerate corner gives a level-1 shift of -46 rows) reaches past it; the rows next to
+    the shard's edge are then not the reference's, and the corner stage must say so: bit 8 + level of the status word."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, R = 1104, 128, 4, 3, 3
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, -0.7 * i, seed=251)[1]).cuda() for i in (24, 25, 24, 25)]
+    plain = eng.Session(w, h, L, win, "lk_float")
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    plain.set_frame_device(frames[1]); plain.build_pyramid(); plain.run_flow()
+    torch.cuda.synchronize()
+    v1 = float(plain.uv(1).cpu()[1])
+    plain.close()
+    assert abs(v1) > 40, "this pair is expected to have a wild level-1 shift"
+    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R), local_corner=True) for r in range(R)]
+    for s in ranks:
+        s.stream_begin()
+        for f in frames:
+            s.stream_submit(f)
+        while s.stream_drain() != -2:
+            pass
+    torch.cuda.synchronize()
+    status = [s.corner_status() for s in ranks]
+    for s in ranks:
+        s.close()
+    # (rank 0 holds the top rows of every level, which is where an upward shift lands: the ranks below it must flag level 1)
+    assert any((st >> 8) & 0b10 for st in status[1:]), [hex(st) for st in status]
+
+
 def test_stream_submit_frames_equals_single_submits(eng):
     """ofx_session_stream_submit_frames(n frames) == n calls of ofx_session_stream_submit: same pairs reported, same bits;
     group sizes that do and do not line up with the frames per launch."""
