@@ -87,8 +87,8 @@ def main():
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
     args = ap.parse_args()
-    # A stream tick carries `batch` frames and a step is one frame: the timed K steps (and the W warm-up steps before them)
-    # must be whole ticks, or frames would be counted that were only queued.  Use the largest batch that divides both.
+    # A stream tick carries `batch` frames and a step is one frame: the timed K steps must be whole ticks, or frames would be
+    # counted that were only queued.  Use the largest batch that divides K.
     args.borrow = not args.copy_frames
     if args.batch == 0:
         from cuda_optical_flow_2_amd.engine import suggest_stream_batch
@@ -96,9 +96,11 @@ def main():
         bw, bh, bl, bwin = WORKLOADS[args.workload]
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
         args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow)
-    while args.batch > 1 and (args.steps % args.batch or args.warmup % args.batch or
+    while args.batch > 1 and (args.steps % args.batch or
                               args.batch * WORKLOADS[args.workload][2] > 40):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2
+    # (the warm-up is rounded UP to whole ticks -- a few more untimed steps -- so that only K constrains the frames per launch)
+    warmup_steps = (args.warmup + args.batch - 1) // args.batch * args.batch
 
     import numpy as np
     import torch
@@ -229,20 +231,20 @@ def main():
             step(i_ramp)
             i_ramp += 1
         torch.cuda.synchronize()
-    for i in range(args.warmup):
+    for i in range(warmup_steps):
         step(i)
     fence()
     # pass 1 -- the throughput: EXACTLY args.steps steps, no instrumentation inside the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(warmup_steps + i)
     fence()
     dt = time.perf_counter() - t0
     # pass 2 -- the dominant kernel's duration: the same steps again with a pair of HIP events recorded around every
     # launch of that kernel on the stream it runs on (two extra packets per launch, so this pass is not the one timed above)
     sess.timing(args.steps * max(1, args.iters))
     for i in range(args.steps):
-        step(args.warmup + args.steps + i)
+        step(warmup_steps + args.steps + i)
     fence()
     k_avg_us, k_min_us, k_n = sess.timing_read()
     sess.timing(0)
@@ -320,7 +322,7 @@ def main():
             "dtype": "i32/f64",
             "data": "synthetic",
             "config": {
-                "untimed_clock_ramp_s": ramp_s,
+                "untimed_clock_ramp_s": ramp_s, "warmup_steps_run": warmup_steps,
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
