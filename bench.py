@@ -326,7 +326,8 @@ def main():
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
-                "frames": (f"a ring of {ring_n} distinct device buffers, " +
+                "frames": ("four resident device buffers, level 0 copied into the session per pair"
+                           if driver is None and args.path != "stream" else f"a ring of {ring_n} distinct device buffers, " +
                            (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {3 * args.batch} further submits)"
                             if args.borrow and ((driver is None and args.path == "stream") or (driver is not None and args.shard_corner == "local" and args.shard_halo != "exchange"))
                             else "level 0 copied into the session")),
