@@ -148,7 +148,7 @@ def main():
     # hand them over: long enough for ofx_params.borrow_frames (a buffer stays untouched for 3 * batch further submits), and
     # large enough that a frame is not still sitting in the 256 MB Infinity Cache when it comes round again (four buffers
     # would be: with borrowed frames that alone made the LK stage ~10 % faster).  Contents repeat every four buffers.
-    ring_n = (3 * max(args.batch, 4) + 4 + 3) // 4 * 4
+    ring_n = int(os.environ.get("OFX_BENCH_RING", "0")) or (3 * max(args.batch, 4) + 4 + 3) // 4 * 4  # (experiments: other ring sizes)
     d_ring = [d_frames[i % nframes] if i < nframes else d_frames[i % nframes].clone() for i in range(ring_n)]
     # the frames of one tick go down in one call (ofx_session_stream_submit_frames): step i of a tick only counts, the tick's
     # last step submits -- the per-frame FFI crossing is what limits small frames and the ranks of a sharded pair.
