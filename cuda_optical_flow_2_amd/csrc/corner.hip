@@ -21,7 +21,48 @@ __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
     corner_wave<MODE>(A, (int)threadIdx.x, f0, cache);
 }
 
+// Row-sharded sessions that RECEIVE their shift vectors (rank 0's corner kernel + broadcast) check them here: the level
+// kernel reads next at row (int)(y + v) for the rows y its stencils touch, and a target inside the image must be a row the
+// shard's buffers hold.  Same rule and same status bit (8 + k) as the corner wave applies for local_corner sessions.
+struct MarginArgs {
+    const float *uv;
+    int *status;
+    int levels;
+    int h[OFX_MAX_LEVELS];
+    int rows[OFX_MAX_LEVELS][4]; // need0, need1, valid0, valid1
+};
+
+__global__ __launch_bounds__(64) void shard_margin_kernel(const MarginArgs A)
+{
+    const int k = (int)threadIdx.x;
+    if (k >= A.levels - 1) return; // the top level is not shifted
+    const float v = A.uv[2 * k + 1];
+    const int need0 = A.rows[k][0], need1 = A.rows[k][1], valid0 = A.rows[k][2], valid1 = A.rows[k][3];
+    if (!(need1 > need0) || v != v) return;
+    const float t0 = (float)need0 + v, t1 = (float)(need1 - 1) + v;
+    if (t1 > -1.0f && t0 < (float)A.h[k]) {
+        const int lo = max(0, (int)floorf(t0)), hi = min(A.h[k] - 1, (int)floorf(t1));
+        if (lo <= hi && (lo < valid0 || hi >= valid1)) atomicOr(A.status, 1 << (8 + k));
+    }
+}
+
 } // namespace
+
+int ofx_shard_margin_check(const float *d_uv, int levels, const int *heights, const int *shard_rows, int *d_status, void *stream)
+{
+    OFX_REQUIRE(d_uv && heights && shard_rows && d_status && levels >= 1 && levels <= OFX_MAX_LEVELS, "ofx_shard_margin_check: bad arguments");
+    MarginArgs a{};
+    a.uv = d_uv;
+    a.status = d_status;
+    a.levels = levels;
+    for (int k = 0; k < levels; ++k) {
+        a.h[k] = heights[k];
+        for (int j = 0; j < 4; ++j) a.rows[k][j] = shard_rows[4 * k + j];
+    }
+    hipLaunchKernelGGL(shard_margin_kernel, dim3(1), dim3(64), 0, ofx_stream(stream), a);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
 
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
                     const int *shard_rows, CornerArgs *out)

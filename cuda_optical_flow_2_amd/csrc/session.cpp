@@ -64,8 +64,26 @@ struct ofx_session {
     // optional timing of the level-0 fused LK launch: event pairs recorded on the launch stream
     bool timing = false;
     std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind; // OFX_TIME_* of event pair i
     size_t ev_used = 0;
+    hipEvent_t ev_frame = nullptr; // staged path: the caller's frame is complete (caller's stream -> aux)
+    int n_sets = 0;                // image sets allocated (3B + 2; the pair-at-a-time paths rotate the first three)
 };
+
+// Runs `launch` bracketed by a pair of timing events of kind `kind` when the session is armed (ofx_session_timing).
+template <typename F>
+static int timed_launch(ofx_session *s, int kind, void *stream, F &&launch)
+{
+    const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
+    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
+    OFX_TRY(launch());
+    if (timed) {
+        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
+        s->ev_kind[s->ev_used / 2] = kind;
+        s->ev_used += 2;
+    }
+    return OFX_OK;
+}
 
 static void repoint(ofx_session *s)
 {
@@ -116,6 +134,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     ofx_session *s = new (std::nothrow) ofx_session();
     OFX_REQUIRE(s != nullptr, "ofx_session_create: out of host memory");
     s->p = *p;
+    // image sets: the stream pipeline cycles through 3B + 2 of them (B = frames per tick; a session created without a
+    // stream_batch may still stream one frame per tick), the pair-at-a-time paths rotate the first three
+    const int n_sets = 3 * (p->stream_batch >= 2 ? p->stream_batch : 1) + 2;
+    s->n_sets = n_sets;
     size_t total = 0;
     std::vector<size_t> off_plane[kSets + 2], off_flow, off_flow2, flow_stride;
     for (int k = 0; k < p->levels; ++k) {
@@ -145,7 +167,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
-        for (int t = 0; t < kSets + 2; ++t) { // image sets + 2 shifted sets
+        for (int t = 0; t < n_sets + 2; ++t) { // image sets + 2 shifted sets
             off_plane[t].push_back(total);
             total += plane_bytes;
         }
@@ -169,7 +191,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->ph[k] = ph0 >> k;
             s->ppitch[k] = (int)align_up((size_t)s->pw[k], 64);
             const size_t bytes = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
-            for (int t = 0; t < kSets; ++t) {
+            for (int t = 0; t < n_sets; ++t) {
                 off_patch[t].push_back(total);
                 total += bytes;
             }
@@ -187,8 +209,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     total += kAlign;
     const size_t off_uv = total;
     total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * kUvSlots, kAlign);
-    const size_t off_staging = total;
-    total += align_up((size_t)p->width * (size_t)p->height * 3, kAlign);
+    const size_t off_staging = total; // one 3-channel frame for ofx_session_set_frame_host_3ch (unsharded sessions only)
+    if (!p->sharded) total += align_up((size_t)p->width * (size_t)p->height * 3, kAlign);
 
     hipError_t e = hipMalloc(&s->arena, total);
     if (e != hipSuccess) {
@@ -206,8 +228,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     }
     uint8_t *base = static_cast<uint8_t *>(s->arena);
     for (int k = 0; k < p->levels; ++k) {
-        for (int t = 0; t < kSets; ++t) s->img[t][k] = base + off_plane[t][k];
-        for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[kSets + t][k];
+        for (int t = 0; t < n_sets; ++t) s->img[t][k] = base + off_plane[t][k];
+        for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[n_sets + t][k];
         s->flowset[0][k] = reinterpret_cast<float *>(base + off_flow[k]);
         for (int t = 1; t < kMaxBatch; ++t)
             s->flowset[t][k] = reinterpret_cast<float *>(base + (t < p->stream_batch ? off_flow2[k] + (size_t)(t - 1) * flow_stride[k] : off_flow[k]));
@@ -215,10 +237,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     }
     if (p->local_corner)
         for (int k = 0; k < p->levels; ++k)
-            for (int t = 0; t < kSets; ++t) s->pimg[t][k] = base + off_patch[t][k];
+            for (int t = 0; t < n_sets; ++t) s->pimg[t][k] = base + off_patch[t][k];
     s->corner_status = reinterpret_cast<int *>(base + off_status);
     s->uv = reinterpret_cast<float *>(base + off_uv);
-    s->staging = base + off_staging;
+    s->staging = p->sharded ? nullptr : base + off_staging;
     repoint(s);
     *out = s;
     return OFX_OK;
@@ -228,16 +250,14 @@ extern "C" int ofx_session_destroy(ofx_session *s)
 {
     if (!s) return OFX_OK;
     hipError_t e = hipSuccess;
-    for (hipEvent_t ev : s->ev) (void)hipEventDestroy(ev);
     (void)hipSetDevice(s->p.device);
+    for (hipEvent_t ev : s->ev) (void)hipEventDestroy(ev);
+    if (s->ev_frame) (void)hipEventDestroy(s->ev_frame);
     if (s->ev_ready) (void)hipEventDestroy(s->ev_ready);
     for (hipEvent_t ev : s->ev_set_done)
         if (ev) (void)hipEventDestroy(ev);
     if (s->aux) (void)hipStreamDestroy(s->aux);
-    if (s->arena) {
-        (void)hipSetDevice(s->p.device);
-        e = hipFree(s->arena);
-    }
+    if (s->arena) e = hipFree(s->arena);
     delete s;
     if (e != hipSuccess) {
         ofx_set_error("ofx_session_destroy: hipFree: %s", hipGetErrorString(e));
@@ -301,7 +321,8 @@ static int build_pyramid(ofx_session *s, void *stream)
             lv[k] = s->plane[1][k];
             pitches[k] = s->pitch[k];
         }
-        return ofx_pyramid_1ch(s->plane[1][0], s->pitch0_next(), s->w[0], s->h[0], lv, pitches, s->p.levels, stream);
+        return timed_launch(s, OFX_TIME_PYRAMID, stream,
+                            [&] { return ofx_pyramid_1ch(s->plane[1][0], s->pitch0_next(), s->w[0], s->h[0], lv, pitches, s->p.levels, stream); });
     }
     for (int k = 1; k < s->p.levels; ++k) OFX_TRY(ofx_session_downsample_level(s, k, stream));
     return OFX_OK;
@@ -347,14 +368,9 @@ extern "C" int ofx_session_run_level(ofx_session *s, int level, void *stream)
         next = s->plane[2][level];
     }
     const ofx_geom g = level_geom(s, level, s->own0[level], s->own1[level]);
-    const bool timed = s->timing && level == 0 && s->ev_used + 2 <= s->ev.size();
-    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
-    OFX_TRY(ofx_lk_level(s->plane[0][level], next, &g, s->p.window, s->p.mode, s->flow[level], s->own0[level], stream));
-    if (timed) {
-        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
-        s->ev_used += 2;
-    }
-    return OFX_OK;
+    auto launch = [&] { return ofx_lk_level(s->plane[0][level], next, &g, s->p.window, s->p.mode, s->flow[level], s->own0[level], stream); };
+    if (level != 0) return launch();
+    return timed_launch(s, OFX_TIME_LK, stream, launch);
 }
 
 extern "C" int ofx_session_timing(ofx_session *s, int max_launches)
@@ -362,6 +378,7 @@ extern "C" int ofx_session_timing(ofx_session *s, int max_launches)
     OFX_REQUIRE(s && max_launches >= 0, "ofx_session_timing: bad arguments");
     for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     s->ev.clear();
+    s->ev_kind.assign((size_t)max_launches, 0);
     s->ev_used = 0;
     s->timing = max_launches > 0;
     for (int i = 0; i < 2 * max_launches; ++i) {
@@ -372,23 +389,39 @@ extern "C" int ofx_session_timing(ofx_session *s, int max_launches)
     return OFX_OK;
 }
 
-extern "C" int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int *launches)
+// average / minimum over the recorded launches whose kind is in `kind_mask` (bit OFX_TIME_*); does not re-arm
+static int timing_stats(ofx_session *s, unsigned kind_mask, double *avg_us, double *min_us, int *launches)
 {
-    OFX_REQUIRE(s && avg_us && launches, "ofx_session_timing_read: bad arguments");
     double sum = 0, mn = 1e30;
-    const int n = (int)(s->ev_used / 2);
-    for (int i = 0; i < n; ++i) {
+    int n = 0;
+    for (size_t i = 0; i < s->ev_used / 2; ++i) {
+        if (!((kind_mask >> s->ev_kind[i]) & 1u)) continue;
         OFX_HIP(hipEventSynchronize(s->ev[2 * i + 1]));
         float ms = 0;
         OFX_HIP(hipEventElapsedTime(&ms, s->ev[2 * i], s->ev[2 * i + 1]));
         sum += ms * 1e3;
         if (ms * 1e3 < mn) mn = ms * 1e3;
+        ++n;
     }
     *avg_us = n ? sum / n : 0.0;
     if (min_us) *min_us = n ? mn : 0.0;
     *launches = n;
+    return OFX_OK;
+}
+
+extern "C" int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int *launches)
+{
+    OFX_REQUIRE(s && avg_us && launches, "ofx_session_timing_read: bad arguments");
+    // the dominant launches: the fused LK launches of the pair-at-a-time paths, the stream tick of the stream pipeline
+    OFX_TRY(timing_stats(s, (1u << OFX_TIME_LK) | (1u << OFX_TIME_LK_ACC) | (1u << OFX_TIME_STREAM), avg_us, min_us, launches));
     s->ev_used = 0;
     return OFX_OK;
+}
+
+extern "C" int ofx_session_timing_read_kind(ofx_session *s, int kind, double *avg_us, double *min_us, int *launches)
+{
+    OFX_REQUIRE(s && avg_us && launches && kind >= 0 && kind < OFX_TIME_KINDS, "ofx_session_timing_read_kind: bad arguments");
+    return timing_stats(s, 1u << kind, avg_us, min_us, launches);
 }
 
 // Shift vectors of every level at once (ofx_corner_flows); meaningful on the rank whose buffers start at row 0.
@@ -402,7 +435,7 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
     ofx_lk_desc d[OFX_MAX_LEVELS];
     for (int k = 0; k < s->p.levels; ++k)
         d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr};
-    return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv_cur(), stream);
+    return timed_launch(s, OFX_TIME_CORNER, stream, [&] { return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv_cur(), stream); });
 }
 
 // Every level's fused LK in one launch, using the uv slots as they stand; below the top level the kernel reads `next`
@@ -410,14 +443,8 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
 // one multi-level LK launch, bracketed by timing events when the session is armed (ofx_session_timing)
 static int timed_lk_launch(ofx_session *s, const ofx_lk_desc *lk, int nl, void *stream)
 {
-    const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
-    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
-    OFX_TRY(ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream));
-    if (timed) {
-        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
-        s->ev_used += 2;
-    }
-    return OFX_OK;
+    return timed_launch(s, lk[0].accumulate ? OFX_TIME_LK_ACC : OFX_TIME_LK, stream,
+                        [&] { return ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream); });
 }
 
 static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
@@ -438,7 +465,7 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
     int ns = 0;
     for (int k = L - 2; k >= 0; --k)
         sd[ns++] = ofx_shift_desc{s->plane[1][k], s->sh[0][k], level_geom(s, k, 0, s->h[k]), uv + 2 * k};
-    if (ns) OFX_TRY(ofx_shift_levels(sd, ns, stream));
+    if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
     auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
     int nl = 0;
     for (int k = L - 1; k >= 0; --k)
@@ -452,10 +479,23 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
             lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1};
             ++nl;
         }
-        OFX_TRY(ofx_warp_levels(wd, nl, stream));
+        OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nl, stream); }));
         OFX_TRY(timed_lk_launch(s, lk, nl, stream));
     }
     return OFX_OK;
+}
+
+// per level: the image rows the LK stencils of this shard's own rows touch (before the shift) and the rows its buffers hold
+static void shard_reach(const ofx_session *s, int (*rows)[4])
+{
+    const int reach = s->p.window / 2 + 1; // the LK stencil of the own rows reaches radius + 1 rows beyond them
+    for (int k = 0; k < s->p.levels; ++k) {
+        const int n0 = s->own0[k] - reach, n1 = s->own1[k] + reach;
+        rows[k][0] = n0 < 0 ? 0 : n0;
+        rows[k][1] = n1 > s->h[k] ? s->h[k] : n1;
+        rows[k][2] = s->buf0[k]; // (rows outside comp but inside buf are the caller's to fill: the halo exchange)
+        rows[k][3] = s->buf1[k];
+    }
 }
 
 extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
@@ -464,6 +504,13 @@ extern "C" int ofx_session_run_levels(ofx_session *s, void *stream)
     if (!s->have_prev || !s->have_next) {
         ofx_set_error("ofx_session_run_levels: need a previous and a next frame");
         return OFX_E_STATE;
+    }
+    if (s->p.sharded && !s->p.local_corner && s->p.levels > 1) {
+        // the shift vectors were computed elsewhere (rank 0's corner kernel, then the broadcast): check them against this
+        // shard's halo on the device, without a host round trip (ofx_session_corner_status reads the word)
+        int rows[OFX_MAX_LEVELS][4];
+        shard_reach(s, rows);
+        OFX_TRY(ofx_shard_margin_check(s->uv_cur(), s->p.levels, s->h, &rows[0][0], s->corner_status, stream));
     }
     return lk_all_levels(s, s->uv_cur(), stream);
 }
@@ -512,6 +559,7 @@ static int ensure_pipeline(ofx_session *s)
 {
     if (s->ev_ready) return OFX_OK;
     OFX_HIP(hipEventCreateWithFlags(&s->ev_ready, hipEventDisableTiming));
+    OFX_HIP(hipEventCreateWithFlags(&s->ev_frame, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) OFX_HIP(hipEventCreateWithFlags(&s->ev_set_done[i], hipEventDisableTiming));
     // highest priority: the staging kernels are tiny and must slip in between the LK waves of the previous pair
     int prio_lo = 0, prio_hi = 0;
@@ -528,7 +576,8 @@ extern "C" int ofx_session_aux_stream(ofx_session *s, void **stream)
     return OFX_OK;
 }
 
-// staging, part 1: frame -> next image set, pyramid.  `d_gray1` must be complete in HBM when this is called.
+// staging, part 1: frame -> next image set, pyramid.  `d_gray1` is read on the staging stream: the caller orders that stream
+// behind the frame's producer (ofx_session_submit_device does it with an event on its `stream` argument).
 extern "C" int ofx_session_stage_frame(ofx_session *s, const uint8_t *d_gray1, int pitch, void *aux_stream)
 {
     OFX_REQUIRE(s && d_gray1, "ofx_session_stage_frame: null argument");
@@ -585,6 +634,11 @@ extern "C" int ofx_session_submit_device(ofx_session *s, const uint8_t *d_gray1,
     OFX_REQUIRE(!s->p.sharded || s->buf0[0] == 0, "ofx_session_submit_device: on a sharded session drive the halves yourself "
                                                    "(stage_frame, corner_flows on the rank holding row 0, broadcast, stage_shift, "
                                                    "solve_staged)");
+    // the frame may still be in production on the caller's stream (an async upload, a decoder or grayscale kernel): the
+    // staging stream reads it, so it is ordered behind everything enqueued on `stream` so far
+    OFX_TRY(ensure_pipeline(s));
+    OFX_HIP(hipEventRecord(s->ev_frame, ofx_stream(stream)));
+    OFX_HIP(hipStreamWaitEvent(s->aux, s->ev_frame, 0));
     OFX_TRY(ofx_session_stage_frame(s, d_gray1, pitch, nullptr));
     OFX_TRY(ofx_session_corner_flows(s, s->aux));
     OFX_TRY(ofx_session_stage_shift(s, nullptr));
@@ -727,15 +781,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         }
         if (s->p.local_corner) {
             C.d_status = s->corner_status;
-            if (s->p.sharded)
-                for (int k = 0; k < L; ++k) {
-                    const int reach = s->p.window / 2 + 1; // the LK stencil of the own rows reaches radius + 1 rows beyond them
-                    const int n0 = s->own0[k] - reach, n1 = s->own1[k] + reach;
-                    C.shard_rows[k][0] = n0 < 0 ? 0 : n0;
-                    C.shard_rows[k][1] = n1 > s->h[k] ? s->h[k] : n1;
-                    C.shard_rows[k][2] = s->cmp0[k];
-                    C.shard_rows[k][3] = s->cmp1[k];
-                }
+            if (s->p.sharded) shard_reach(s, C.shard_rows);
         }
     }
     long newest = -1;
@@ -755,17 +801,20 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         s->reported = newest;
         for (int k = 0; k < L; ++k) s->flow[k] = s->flowset[newest % B][k];
     }
-    static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }(); // timing experiments only
+    bool time_it = g.n_lk > 0;
+#ifdef OFX_EXPERIMENTS
+    // stage ablation for timing experiments (tools/stream_timeline.py): the flows reported complete are then NOT computed, so
+    // the knob only exists in builds made with -DOFX_EXPERIMENTS (OFX_BUILD_DEFS)
+    static const int skip = [] { const char *e = getenv("OFX_STREAM_SKIP"); return e ? atoi(e) : 0; }();
     if (skip & 1) g.n_pyr = 0;
     if (skip & 2) g.n_corner = 0;
     if (skip & 8) g.n_lk = 0;
-    const bool timed = s->timing && (g.n_lk > 0 || (skip & 8)) && s->ev_used + 2 <= s->ev.size();
-    if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
-    OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
-    if (timed) {
-        OFX_HIP(hipEventRecord(s->ev[s->ev_used + 1], ofx_stream(stream)));
-        s->ev_used += 2;
-    }
+    time_it = time_it || (skip & 8);
+#endif
+    if (time_it)
+        OFX_TRY(timed_launch(s, OFX_TIME_STREAM, stream, [&] { return ofx_stream_launch(&g, s->p.window, s->p.mode, stream); }));
+    else
+        OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
     s->stream_n = f0 + B;
     return OFX_OK;
 }
@@ -778,6 +827,10 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
                 "computed from each frame's top-left patch); otherwise drive the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
     OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
+    // staging work of the pair-at-a-time pipelined path may still be in flight on the session's own stream; the stream
+    // pipeline is about to reuse the same image sets from the caller's stream
+    if (s->aux) OFX_HIP(hipStreamSynchronize(s->aux));
+    for (bool &b : s->set_busy) b = false;
     s->stream_n = 0;
     s->stream_frames = -1;
     s->n_held = 0;

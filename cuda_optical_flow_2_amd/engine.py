@@ -218,6 +218,15 @@ class Session:
         check(self.L.ofx_session_timing_read(self._h, C.byref(avg), C.byref(mn), C.byref(n)), "session_timing_read")
         return avg.value, mn.value, n.value
 
+    TIME_KINDS = {"lk": 0, "lk_acc": 1, "warp": 2, "stream": 3, "shift": 4, "corner": 5, "pyramid": 6}   # OFX_TIME_*
+
+    def timing_read_kind(self, kind: str):
+        """(average us, minimum us, launches) of one kind of launch; call before timing_read, which re-arms."""
+        avg, mn, n = C.c_double(), C.c_double(), C.c_int()
+        check(self.L.ofx_session_timing_read_kind(self._h, self.TIME_KINDS[kind], C.byref(avg), C.byref(mn), C.byref(n)),
+              "session_timing_read_kind")
+        return avg.value, mn.value, n.value
+
     # ---- buffers
     def plane(self, which: int, level: int):
         """(torch uint8 view [rows, pitch], Geom) of plane 0=prev 1=next 2=shifted."""

@@ -105,6 +105,7 @@ _SIGS = {
     "ofx_session_get_flow_host": [_vp, _i, _vp, _vp],
     "ofx_session_timing": [_vp, _i],
     "ofx_session_timing_read": [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)],
+    "ofx_session_timing_read_kind": [_vp, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)],
     "ofx_calc_opt_flow_host": [_vp, _vp, _i, _i, C.POINTER(_vp), _i, _i, _i, _i],
 }
 _RESTYPE = {"ofx_generate_gaussian_kernel": None}

@@ -137,6 +137,9 @@ class HipBackend:
             self._aux_ptr = self.session.aux_stream_ptr()
             self._aux = torch.cuda.ExternalStream(self._aux_ptr)
         s = self.session
+        # the frame may still be in production on the caller's stream (async upload, decoder, grayscale kernel): the
+        # staging stream reads it, so it is ordered behind everything enqueued there so far
+        self._aux.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._aux):
             s.stage_frame(frame, self._aux_ptr)
             if rank == 0:
@@ -288,6 +291,13 @@ class ShardedFlow:
             self.assert_margin()
         b.run_levels()
         b.swap()
+
+    def corner_status(self) -> int:
+        """Device status word of this rank's session, read and cleared (synchronises): 0 = every pair so far is exactly
+        the unsharded result; bit k = level k's shift left the top-left patch (local corner mode), bit 8 + k = level k's
+        vertical shift reached image rows beyond this shard's halo (any mode; the `margin` rows of the plan).  bench.py
+        and long-running drivers check it after a batch of pairs instead of syncing per pair (assert_margin)."""
+        return self.session.corner_status() if self.session is not None else 0
 
     def assert_margin(self):
         """The shift is exact while every level's vertical shift stays within the halo margin (host sync: tests only)."""

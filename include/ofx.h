@@ -386,6 +386,18 @@ int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst, void *str
  * launches (0 disarms); read returns the average/minimum duration in microseconds and re-arms. */
 int ofx_session_timing(ofx_session *s, int max_launches);
 int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int *launches);
+/* While armed, EVERY launch the session issues is bracketed and tagged with its kind; ofx_session_timing_read averages the
+ * dominant ones (LK, LK_ACC, STREAM) and re-arms, ofx_session_timing_read_kind reads one kind and leaves the records in place
+ * (call it before ofx_session_timing_read). */
+#define OFX_TIME_LK 0      /* fused LK launch that writes the flow (all levels, or level 0 of run_level) */
+#define OFX_TIME_LK_ACC 1  /* fused LK launch of a refinement iteration (flow += result) */
+#define OFX_TIME_WARP 2    /* bilinear warp of a refinement iteration, all levels */
+#define OFX_TIME_STREAM 3  /* one tick of the stream pipeline */
+#define OFX_TIME_SHIFT 4   /* stand-alone global shift of all levels (refinement iterations only) */
+#define OFX_TIME_CORNER 5  /* corner kernel */
+#define OFX_TIME_PYRAMID 6 /* fused pyramid launch */
+#define OFX_TIME_KINDS 7
+int ofx_session_timing_read_kind(ofx_session *s, int kind, double *avg_us, double *min_us, int *launches);
 
 /* ---- host-pointer convenience used by the gpu:: compat surface ------------ */
 /* gpu::calc_opt_flow (OptFlowGpu.cuh:33): host 3ch images in, host flow pyramid in/out. */
