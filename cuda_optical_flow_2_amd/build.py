@@ -19,7 +19,7 @@ OUT = os.path.join(PKG, os.environ.get("OFX_BUILD_OUT", "libofx_hip.so"))  # exp
 OBJ = os.path.join(PKG, "csrc", "_obj" + os.environ.get("OFX_BUILD_TAG", ""))
 ARCH = "gfx950"
 
-SOURCES = ["lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp", "compat_gpu.cpp"]
+SOURCES = ["lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp", "compat_gpu.cpp", "compat_cpu.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
 # buys nothing on gfx950 (packed fp32 issues at half the rate of scalar fp32; tools/ubench/valu_rates.hip)

@@ -31,6 +31,20 @@ GPU_SYMBOLS = {
     "calc_opt_flow": "_ZN3gpu13calc_opt_flowEPKhPhiiPPfii",
     "bilinear_filter": "_ZN3gpu15bilinear_filterEPhS0_S0_iiiidd",
 }
+CPU_SYMBOLS = {   # the reference's OptFlowCpu.hpp:3-184
+    "sub_arr": "_ZN3cpu7sub_arrEPhS0_iS0_",
+    "grayscale_avg_cpu": "_ZN3cpu17grayscale_avg_cpuEPKhPhii",
+    "conv_3ch": "_ZN3cpu8conv_3chEPKhPKfPhiiii",
+    "conv_3ch_to_1ch": "_ZN3cpu15conv_3ch_to_1chEPKhiiPhPKfii",
+    "downscale_gaussian": "_ZN3cpu18downscale_gaussianEPhiiS0_PKfii",
+    "gauss_pyramid": "_ZN3cpu13gauss_pyramidEPPhiiiPKfii",
+    "srm_1ch": "_ZN3cpu7srm_1chEPKhS1_iiiiPi",
+    "srm_3ch": "_ZN3cpu7srm_3chEPhS0_iiiiPi",
+    "shift_back_pyramid": "_ZN3cpu18shift_back_pyramidEPKhiiiiPPfPh",
+    "inverse_matrix": "_ZN3cpu14inverse_matrixEPiS0_S0_S0_S0_PPfiii",
+    "calc_optical_flow": "_ZN3cpu17calc_optical_flowEPKhPhiiPPfii",
+    "bilinear_filter_3ch": "_ZN3cpu19bilinear_filter_3chEPhS0_S0_iiiidd",
+}
 UTILS_SYMBOLS = {
     "cleanup_outliers": "_ZN5utils16cleanup_outliersEPhii",
     "upscale_3ch": "_ZN5utils11upscale_3chEPhiiiS0_",
@@ -167,4 +181,165 @@ class GpuCompat:
         flow = [np.zeros((h >> k, w >> k, 2), np.float32) for k in range(levels)]
         for k in range(levels - 1, -1, -1):
             self.calc_opt_flow(pp[k], npyr[k], flow, k, levels)
+        return flow, pp, npyr
+
+
+    def conv_1d_3ch(self, src3):
+        src3 = _c(src3, np.uint8).copy()
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3)
+        self._f("conv_1d_3ch")(_p(src3, _u8p), w, h, _p(d, _u8p))
+        self._done("conv_1d_3ch")
+        return d
+
+
+class UtilsCompat:
+    """namespace utils of libofx_hip.so (include/OptFlowUtils.hpp) by mangled name."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def _f(self, name):
+        f = getattr(self.lib, UTILS_SYMBOLS[name])
+        f.restype = None
+        return f
+
+    def cleanup_outliers(self, img1):
+        d = _c(img1, np.uint8).copy()
+        h, w = d.shape
+        self._f("cleanup_outliers")(_p(d, _u8p), w, h)
+        return d
+
+    def upscale(self, src, n):
+        src = _c(src, np.uint8).copy()
+        h, w = src.shape[:2]
+        d = np.zeros((h << n, w << n) + ((3,) if src.ndim == 3 else ()), np.uint8)
+        self._f("upscale_3ch" if src.ndim == 3 else "upscale_1ch")(_p(src, _u8p), w, h, n, _p(d, _u8p))
+        return d
+
+    def generate_gaussian_kernel(self, sigma, ks):
+        n = ks if ks % 2 else ks + 1
+        d = np.zeros((n, n), np.float64)
+        self._f("generate_gaussian_kernel")(C.c_double(sigma), C.c_int(ks), d.ctypes.data_as(C.POINTER(C.c_double)))
+        return d
+
+
+class CpuCompat:
+    """namespace cpu of libofx_hip.so (include/OptFlowCpu.hpp): the reference's CPU call surface, executed on the device."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def _f(self, name):
+        f = getattr(self.lib, CPU_SYMBOLS[name])
+        f.restype = None
+        return f
+
+    def _done(self, what):
+        rc = self.lib.gpu_compat_last_status()
+        if rc != 0:
+            raise _lib.OfxError(f"cpu::{what} failed (code {rc}): {self.lib.ofx_last_error().decode()}")
+
+    def sub_arr(self, a, b):
+        a, b = _c(a, np.uint8).copy(), _c(b, np.uint8).copy()
+        d = np.zeros_like(a)
+        self._f("sub_arr")(_p(a, _u8p), _p(b, _u8p), a.size, _p(d, _u8p))
+        self._done("sub_arr")
+        return d
+
+    def grayscale_avg_cpu(self, src3):
+        src3 = _c(src3, np.uint8)
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3)
+        self._f("grayscale_avg_cpu")(_p(src3, _u8p), _p(d, _u8p), w, h)
+        self._done("grayscale_avg_cpu")
+        return d
+
+    def conv_3ch(self, src3, mask, mw, mh):
+        src3, mask = _c(src3, np.uint8), _c(mask, np.float32)
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3)
+        self._f("conv_3ch")(_p(src3, _u8p), _p(mask, _f32p), _p(d, _u8p), w, h, mw, mh)
+        self._done("conv_3ch")
+        return d
+
+    def conv_3ch_to_1ch(self, src3, mask, mw=3, mh=3):
+        src3, mask = _c(src3, np.uint8), _c(mask, np.float32)
+        h, w, _ = src3.shape
+        d = np.zeros((h, w), np.uint8)
+        self._f("conv_3ch_to_1ch")(_p(src3, _u8p), w, h, _p(d, _u8p), _p(mask, _f32p), mw, mh)
+        self._done("conv_3ch_to_1ch")
+        return d
+
+    def downscale_gaussian(self, src3, mask, mw=3, mh=3):
+        src3, mask = _c(src3, np.uint8).copy(), _c(mask, np.float32)
+        sh, sw, _ = src3.shape
+        d = np.zeros((sh >> 1, sw >> 1, 3), np.uint8)
+        self._f("downscale_gaussian")(_p(src3, _u8p), sw >> 1, sh >> 1, _p(d, _u8p), _p(mask, _f32p), mw, mh)
+        self._done("downscale_gaussian")
+        return d
+
+    def gauss_pyramid(self, img3, levels, mask, mw=3, mh=3):
+        img3, mask = _c(img3, np.uint8), _c(mask, np.float32)
+        h, w, _ = img3.shape
+        pyr = [img3.copy()] + [np.zeros((h >> k, w >> k, 3), np.uint8) for k in range(1, levels)]
+        self._f("gauss_pyramid")(_ptrs(pyr, C.c_uint8), w, h, levels, _p(mask, _f32p), mw, mh)
+        self._done("gauss_pyramid")
+        return pyr
+
+    def srm_1ch(self, a, b, ww, wh):
+        a, b = _c(a, np.uint8), _c(b, np.uint8)
+        h, w = a.shape
+        d = np.zeros((h, w), np.int32)
+        self._f("srm_1ch")(_p(a, _u8p), _p(b, _u8p), w, h, ww, wh, _p(d, _i32p))
+        self._done("srm_1ch")
+        return d
+
+    def srm_3ch(self, a3, b3, ww, wh):
+        a3, b3 = _c(a3, np.uint8).copy(), _c(b3, np.uint8).copy()
+        h, w, _ = a3.shape
+        d = np.zeros((h, w, 3), np.int32)
+        self._f("srm_3ch")(_p(a3, _u8p), _p(b3, _u8p), w, h, ww, wh, _p(d, _i32p))
+        self._done("srm_3ch")
+        return d
+
+    def shift_back_pyramid(self, src3, level, max_level, flow_pyr, dest_init=None):
+        src3 = _c(src3, np.uint8)
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3) if dest_init is None else _c(dest_init, np.uint8).copy()
+        fl = [_c(f, np.float32) if f is not None else np.zeros(2, np.float32) for f in flow_pyr]
+        self._f("shift_back_pyramid")(_p(src3, _u8p), w, h, level, max_level, _ptrs(fl, C.c_float), _p(d, _u8p))
+        self._done("shift_back_pyramid")
+        return d
+
+    def inverse_matrix(self, sxx, syy, sxy, sxt, syt):
+        s = [_c(x, np.int32).copy() for x in (sxx, syy, sxy, sxt, syt)]
+        h, w = s[0].shape
+        flow = np.zeros((h, w, 2), np.float32)
+        self._f("inverse_matrix")(*[_p(x, _i32p) for x in s], _ptrs([flow], C.c_float), 0, w, h)
+        self._done("inverse_matrix")
+        return flow
+
+    def calc_optical_flow(self, prev3, next3, flow_pyr, level, max_level):
+        prev3, next3 = _c(prev3, np.uint8), _c(next3, np.uint8).copy()
+        h, w, _ = prev3.shape
+        self._f("calc_optical_flow")(_p(prev3, _u8p), _p(next3, _u8p), w, h, _ptrs(flow_pyr, C.c_float), level, max_level)
+        self._done("calc_optical_flow")
+        return flow_pyr[level]
+
+    def bilinear_filter_3ch(self, src3, gray3, ww, wh, sigma_s, sigma_b):
+        src3, gray3 = _c(src3, np.uint8).copy(), _c(gray3, np.uint8).copy()
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3)
+        self._f("bilinear_filter_3ch")(_p(src3, _u8p), _p(gray3, _u8p), _p(d, _u8p), w, h, ww, wh, C.c_double(sigma_s), C.c_double(sigma_b))
+        self._done("bilinear_filter_3ch")
+        return d
+
+    def flow_pair(self, prev3, next3, levels, mask):
+        """main.cu:246-262 with the cpu:: alternates (main.cu:251,261) swapped in"""
+        pp, npyr = self.gauss_pyramid(prev3, levels, mask), self.gauss_pyramid(next3, levels, mask)
+        h, w, _ = prev3.shape
+        flow = [np.zeros((h >> k, w >> k, 2), np.float32) for k in range(levels)]
+        for k in range(levels - 1, -1, -1):
+            self.calc_optical_flow(pp[k], npyr[k], flow, k, levels)
         return flow, pp, npyr

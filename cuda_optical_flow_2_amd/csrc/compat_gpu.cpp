@@ -8,6 +8,7 @@
 
 #include "OptFlowGpu.cuh"
 #include "OptFlowUtils.hpp"
+#include "compat_scratch.h"
 #include "kernels.hpp"
 #include "ofx_internal.h"
 
@@ -27,71 +28,18 @@ extern const float GAUS_KERNEL_5x5[25] = {0.00366, 0.01465, 0.02564, 0.01465, 0.
                                           0.05860, 0.01465, 0.00366, 0.01465, 0.02564, 0.01465, 0.00366};
 extern const float GAUS_KERNEL_3x3[9] = {0.0625, 0.125, 0.0625, 0.125, 0.25, 0.125, 0.0625, 0.125, 0.0625};
 
-namespace {
-
-thread_local int g_status = OFX_OK;
-
-// device scratch for one wrapper call; freed on scope exit
-class Scratch {
-  public:
-    ~Scratch()
-    {
-        for (void *p : bufs_) (void)hipFree(p);
-    }
-    template <typename T>
-    T *alloc(size_t count)
-    {
-        void *p = nullptr;
-        if (rc_ != OFX_OK) return nullptr;
-        const hipError_t e = hipMalloc(&p, count * sizeof(T) + 64);
-        if (e != hipSuccess) {
-            ofx_set_error("hipMalloc(%zu bytes): %s", count * sizeof(T), hipGetErrorString(e));
-            rc_ = OFX_E_HIP;
-            return nullptr;
-        }
-        bufs_.push_back(p);
-        return static_cast<T *>(p);
-    }
-    template <typename T>
-    T *upload(const T *host, size_t count)
-    {
-        T *d = alloc<T>(count);
-        if (d) copy(d, host, count * sizeof(T), hipMemcpyHostToDevice);
-        return d;
-    }
-    template <typename T>
-    void download(T *host, const T *dev, size_t count)
-    {
-        if (rc_ == OFX_OK) copy(host, dev, count * sizeof(T), hipMemcpyDeviceToHost);
-    }
-    void run(int rc)
-    {
-        if (rc_ == OFX_OK) rc_ = rc;
-    }
-    bool ok() const { return rc_ == OFX_OK; }
-    int rc() const { return rc_; }
-
-  private:
-    void copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
-    {
-        const hipError_t e = hipMemcpy(dst, src, bytes, kind); // blocking, ordered after the null-stream kernels
-        if (e != hipSuccess) {
-            ofx_set_error("hipMemcpy(%zu bytes): %s", bytes, hipGetErrorString(e));
-            rc_ = OFX_E_HIP;
-        }
-    }
-    std::vector<void *> bufs_;
-    int rc_ = OFX_OK;
-};
-
-bool args_ok(bool cond, const char *who)
+namespace ofx_compat {
+int &status()
 {
-    if (!cond) {
-        ofx_set_error("%s: null pointer or non-positive size", who);
-        g_status = OFX_E_INVALID;
-    }
-    return cond;
+    static thread_local int st = OFX_OK;
+    return st;
 }
+} // namespace ofx_compat
+
+using ofx_compat::args_ok;
+using ofx_compat::Scratch;
+
+namespace {
 
 // 9-tap 1-D filter over the pixel sequence (reference OptFlowGpu.cu:1134-1159, weights from :1164): int accumulators
 // truncated after every tap.  The reference lets taps run up to 4 pixels past the end of the buffer; here taps
@@ -112,7 +60,7 @@ __global__ void conv_1d_3ch_kernel(const unsigned char *src, unsigned char *dst,
 
 } // namespace
 
-extern "C" int gpu_compat_last_status(void) { return g_status; }
+extern "C" int gpu_compat_last_status(void) { return ofx_compat::status(); }
 
 namespace gpu {
 
@@ -124,7 +72,7 @@ void grayscale_avg(const unsigned char *rgb, unsigned char *gray3, int rows, int
     unsigned char *d_in = s.upload(rgb, n), *d_out = s.alloc<unsigned char>(n);
     if (s.ok()) s.run(ofx_grayscale_avg_3ch(d_in, d_out, cols, rows, nullptr));
     s.download(gray3, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 static void conv3(const unsigned char *img3, unsigned char *out3, int w, int h, const float *mask, int mw, int mh, int float_acc,
@@ -136,7 +84,7 @@ static void conv3(const unsigned char *img3, unsigned char *out3, int w, int h, 
     unsigned char *d_in = s.upload(img3, n), *d_out = s.alloc<unsigned char>(n);
     if (s.ok()) s.run(ofx_conv_3ch(d_in, d_out, w, h, mask, mw, mh, float_acc, nullptr));
     s.download(out3, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void conv_3ch_2d(const unsigned char *img3, unsigned char *out3, int w, int h, const float *mask, int mw, int mh)
@@ -162,7 +110,7 @@ static void conv1_u8(const unsigned char *img3, int w, int h, unsigned char *out
     unsigned char *d_in = s.upload(img3, 3 * n), *d_out = s.alloc<unsigned char>(n);
     if (s.ok()) s.run(ofx_conv_3ch_1ch_u8(d_in, w, h, d_out, mask, mw, mh, nullptr));
     s.download(out1, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void conv_3ch_1ch_constant(const unsigned char *img3, int w, int h, unsigned char *out1, const float *mask, int mw, int mh)
@@ -184,7 +132,7 @@ void conv_3ch_1ch_tiled_uchar_float(const unsigned char *img3, int w, int h, flo
     float *d_out = s.alloc<float>(n);
     if (s.ok()) s.run(ofx_conv_3ch_1ch_f32(d_in, w, h, d_out, mask, mw, mh, nullptr));
     s.download(out1, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void conv_1d_3ch(unsigned char *img3, int w, int h, unsigned char *out3)
@@ -202,7 +150,7 @@ void conv_1d_3ch(unsigned char *img3, int w, int h, unsigned char *out3)
         }
     }
     s.download(out3, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void gauss_pyramid(unsigned char **pyramid, int w, int h, int levels, const float *mask, int mw, int mh)
@@ -226,7 +174,7 @@ void gauss_pyramid(unsigned char **pyramid, int w, int h, int levels, const floa
         if (s.ok()) s.run(ofx_downsample_3ch(d[k - 1], d[k], dw, dh, nullptr));
     }
     for (int k = 1; k < levels && s.ok(); ++k) s.download(pyramid[k], d[k], (size_t)(w >> k) * (h >> k) * 3);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 static void srm_u8(const unsigned char *a, const unsigned char *b, int w, int h, int ww, int wh, int *out, const char *who)
@@ -238,7 +186,7 @@ static void srm_u8(const unsigned char *a, const unsigned char *b, int w, int h,
     int *d_o = s.alloc<int>(n);
     if (s.ok()) s.run(ofx_srm_u8(d_a, d_b, w, h, ww, wh, d_o, nullptr));
     s.download(out, d_o, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void srm_1ch(const unsigned char *a, const unsigned char *b, int w, int h, int ww, int wh, int *out)
@@ -260,7 +208,7 @@ void srm_1ch_float(const float *a, const float *b, int w, int h, int ww, int wh,
     float *d_o = s.alloc<float>(n);
     if (s.ok()) s.run(ofx_srm_f32(d_a, d_b, w, h, ww, wh, d_o, nullptr));
     s.download(out, d_o, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void inverse_matrix(int *sumIx2, int *sumIy2, int *sumIxIy, int *sumIxIt, int *sumIyIt, float **optFlowPyramid, int level, int w, int h)
@@ -275,7 +223,7 @@ void inverse_matrix(int *sumIx2, int *sumIy2, int *sumIxIy, int *sumIxIt, int *s
     float *d_f = s.alloc<float>(2 * n);
     if (s.ok()) s.run(ofx_solve_i32(xx, yy, xy, xt, yt, d_f, w, h, OFX_SOLVE_F64, nullptr));
     s.download(optFlowPyramid[level], d_f, 2 * n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void inverse_matrix_float(float *sumIx2, float *sumIy2, float *sumIxIy, float *sumIxIt, float *sumIyIt, float **optFlowPyramid, int level, int w,
@@ -291,13 +239,13 @@ void inverse_matrix_float(float *sumIx2, float *sumIy2, float *sumIxIy, float *s
     float *d_f = s.alloc<float>(2 * n);
     if (s.ok()) s.run(ofx_solve_f32(xx, yy, xy, xt, yt, d_f, w, h, nullptr));
     s.download(optFlowPyramid[level], d_f, 2 * n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 void calc_opt_flow(const unsigned char *prev3, unsigned char *next3, int w, int h, float **optFlowPyramid, int level, int maxLevel)
 {
     // window 19x19 and the Dt_3x3 temporal mask are the reference's constants (OptFlowGpu.cu:1936-1945)
-    g_status = ofx_calc_opt_flow_host(prev3, next3, w, h, optFlowPyramid, level, maxLevel, 19, OFX_MODE_LK_FLOAT);
+    ofx_compat::status() = ofx_calc_opt_flow_host(prev3, next3, w, h, optFlowPyramid, level, maxLevel, 19, OFX_MODE_LK_FLOAT);
 }
 
 void bilinear_filter(unsigned char *img3, unsigned char *gray3, unsigned char *out3, int w, int h, int ww, int wh, double sigmaS, double sigmaB)
@@ -308,7 +256,7 @@ void bilinear_filter(unsigned char *img3, unsigned char *gray3, unsigned char *o
     unsigned char *d_in = s.upload(img3, n), *d_g = (gray3 == img3) ? d_in : s.upload(gray3, n), *d_out = s.alloc<unsigned char>(n);
     if (s.ok()) s.run(ofx_bilateral_3ch(d_in, d_g, d_out, w, h, ww, wh, sigmaS, sigmaB, nullptr));
     s.download(out3, d_out, n);
-    g_status = s.rc();
+    ofx_compat::status() = s.rc();
 }
 
 } // namespace gpu

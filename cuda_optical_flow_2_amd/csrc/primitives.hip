@@ -206,9 +206,136 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t *src3, con
     d[2] = (uint8_t)(int)(acc[2] / wsum);
 }
 
+// ---- the remaining functions of namespace cpu (OptFlowCpu.hpp), so that the cpu:: call surface runs on the device too ------
+
+// cpu::sub_arr, OptFlowCPU.cpp:11-17: byte-wise difference, wrapping modulo 256
+__global__ __launch_bounds__(256) void sub_u8_kernel(const uint8_t *a, const uint8_t *b, size_t n, uint8_t *dst)
+{
+    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) dst[p] = (uint8_t)(a[p] - b[p]);
+}
+
+// cpu::srm_3ch, OptFlowCPU.cpp:202-238: window sum of products per channel.  Its bounds test is `cx > w || cy > h`
+// (:222), so a tap one past the right edge reads the first pixel of the next row (pos = cy*w + w) and a tap one past the
+// bottom edge reads beyond the image; kept as the reference has it for every position that exists (pos < w*h); taps
+// past the end of the buffer -- which the reference reads as whatever follows the allocation -- contribute nothing.
+__global__ __launch_bounds__(256) void srm_3ch_kernel(const uint8_t *a3, const uint8_t *b3, int w, int h, int ww, int wh, int32_t *dst3)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int ox = ww >> 1, oy = wh >> 1;
+    const size_t n = (size_t)w * (size_t)h;
+    int acc[3] = {0, 0, 0};
+    for (int p = 0; p < wh; ++p) {
+        const int cy = y - oy + p;
+        if (cy < 0 || cy > h) continue;
+        for (int q = 0; q < ww; ++q) {
+            const int cx = x - ox + q;
+            if (cx < 0 || cx > w) continue;
+            const size_t t = (size_t)cy * w + cx;
+            if (t >= n) continue;
+            acc[0] += (int)a3[3 * t] * (int)b3[3 * t];
+            acc[1] += (int)a3[3 * t + 1] * (int)b3[3 * t + 1];
+            acc[2] += (int)a3[3 * t + 2] * (int)b3[3 * t + 2];
+        }
+    }
+    int32_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = acc[0];
+    d[1] = acc[1];
+    d[2] = acc[2];
+}
+
+// cpu::downscale_gaussian, OptFlowCPU.cpp:112-148, with the caller's mask (gpu::gauss_pyramid ignores its mask argument,
+// cpu::gauss_pyramid honours it): dst(x,y) = (uchar) sum mask[p][q] * src(2x - mw/2 + q, 2y - mh/2 + p), taps outside the
+// (2w x 2h) source skipped, float accumulators in tap order, x86's float -> int -> low byte conversion
+__global__ __launch_bounds__(256) void downscale_mask_3ch_kernel(const uint8_t *src3, uint8_t *dst3, int w, int h, const MaskArg M)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int pw = w << 1, ph = h << 1;
+    const int sx = (x << 1) - (M.mw >> 1), sy = (y << 1) - (M.mh >> 1);
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int p = 0; p < M.mh; ++p) {
+        const int cy = sy + p;
+        if (cy < 0 || cy >= ph) continue;
+        for (int q = 0; q < M.mw; ++q) {
+            const int cx = sx + q;
+            if (cx < 0 || cx >= pw) continue;
+            const uint8_t *s = src3 + 3 * ((size_t)cy * pw + cx);
+            const float m = M.m[p * M.mw + q];
+            acc[0] += m * (float)s[0];
+            acc[1] += m * (float)s[1];
+            acc[2] += m * (float)s[2];
+        }
+    }
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = (uint8_t)(int)acc[0];
+    d[1] = (uint8_t)(int)acc[1];
+    d[2] = (uint8_t)(int)acc[2];
+}
+
+// cpu::shift_back_pyramid on the 3-channel image, OptFlowCPU.cpp:241-282.  dst arrives holding whatever the caller's
+// buffer held; the first w*h BYTES are overwritten with the source's (the memcpy of :247), then every pixel whose target
+// (int)(x + u), (int)(y + v) lies inside the image takes that pixel's three bytes, the others are left alone.
+// Two passes (the copy first), because the per-pixel pass reads src only and writes dst only.
+__global__ __launch_bounds__(256) void shift_3ch_kernel(const uint8_t *src3, uint8_t *dst3, int w, int h, const float *uv)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const float u = uv[0], v = uv[1];
+    // `int new_pos_x = j + u` converts the float sum; x86 turns NaN and out-of-range values into INT_MIN, which the range
+    // test rejects -- the same pixels are rejected here by testing the float before converting it
+    const float tx = (float)x + u, ty = (float)y + v;
+    if (!(tx > -1.0f && tx < (float)w && ty > -1.0f && ty < (float)h)) return;
+    const int nx = (int)tx, ny = (int)ty;
+    const uint8_t *s = src3 + 3 * ((size_t)ny * w + nx);
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = s[0];
+    d[1] = s[1];
+    d[2] = s[2];
+}
+
 inline dim3 grid2d(int w, int h) { return dim3(ofx_div_up(w, 256), h); }
 
 } // namespace
+
+extern "C" int ofx_sub_u8(const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_dst, void *stream)
+{
+    OFX_REQUIRE(d_a && d_b && d_dst, "ofx_sub_u8: null pointer");
+    if (n == 0) return OFX_OK;
+    hipLaunchKernelGGL(sub_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_a, d_b, n, d_dst);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_srm_3ch_u8(const uint8_t *d_a3, const uint8_t *d_b3, int w, int h, int ww, int wh, int32_t *d_dst3, void *stream)
+{
+    OFX_REQUIRE(d_a3 && d_b3 && d_dst3 && w > 0 && h > 0 && ww > 0 && wh > 0, "ofx_srm_3ch_u8: bad arguments");
+    hipLaunchKernelGGL(srm_3ch_kernel, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_a3, d_b3, w, h, ww, wh, d_dst3);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_downscale_mask_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int dw, int dh, const float *h_mask, int mw, int mh,
+                                      void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst3 && dw > 0 && dh > 0, "ofx_downscale_mask_3ch: bad arguments");
+    MaskArg M;
+    OFX_TRY(make_mask(h_mask, mw, mh, &M, "ofx_downscale_mask_3ch"));
+    hipLaunchKernelGGL(downscale_mask_3ch_kernel, grid2d(dw, dh), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, dw, dh, M);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+extern "C" int ofx_shift_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, const float *d_uv, void *stream)
+{
+    OFX_REQUIRE(d_src3 && d_dst3 && d_uv && w > 0 && h > 0, "ofx_shift_3ch: bad arguments");
+    OFX_REQUIRE(d_src3 != d_dst3, "ofx_shift_3ch: in-place shift is not defined");
+    OFX_HIP(hipMemcpyAsync(d_dst3, d_src3, (size_t)w * (size_t)h, hipMemcpyDeviceToDevice, ofx_stream(stream))); // w*h BYTES, :247
+    hipLaunchKernelGGL(shift_3ch_kernel, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, w, h, d_uv);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
 
 // utils::generate_gaussian_kernel, OptFlowUtils.cpp:68-114 (host side, double)
 extern "C" void ofx_generate_gaussian_kernel(double sigma_s, int ks, double *dst)

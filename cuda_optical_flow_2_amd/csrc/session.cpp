@@ -9,6 +9,7 @@
 #include <new>
 #include <vector>
 
+#include "compat_scratch.h"
 #include "ofx_internal.h"
 
 namespace {
@@ -931,58 +932,55 @@ extern "C" int ofx_calc_opt_flow_host(const uint8_t *h_prev3, const uint8_t *h_n
     OFX_REQUIRE(h_flow_pyr[level] != nullptr, "ofx_calc_opt_flow_host: flow level %d is null", level);
     const size_t n = (size_t)w * (size_t)h;
     const int pitch = (int)align_up((size_t)w, 64);
-    const size_t plane = align_up((size_t)pitch * (size_t)h + 64, kAlign);
-    const size_t img3 = align_up(3 * n, kAlign);
-    const size_t flow_b = align_up(2 * n * sizeof(float), kAlign);
-    const size_t total = 2 * img3 + 3 * plane + flow_b + 2 * kAlign;
-    uint8_t *base = nullptr;
-    OFX_HIP(hipMalloc(reinterpret_cast<void **>(&base), total));
-    int rc = OFX_OK;
-    auto fail = [&](int code) {
-        (void)hipFree(base);
-        return code;
-    };
-    uint8_t *d_p3 = base, *d_n3 = base + img3, *d_p1 = d_n3 + img3, *d_n1 = d_p1 + plane, *d_s1 = d_n1 + plane;
-    float *d_flow = reinterpret_cast<float *>(d_s1 + plane);
-    float *d_coarse = reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(d_flow) + flow_b); // 2 floats per level
+    const size_t plane = (size_t)pitch * (size_t)h + 64;
+    // buffers come from the calling thread's cached arena (compat_scratch.h): no allocation per call in a frame loop
+    ofx_compat::Scratch sc;
+    uint8_t *d_p3 = sc.upload(h_prev3, 3 * n), *d_n3 = sc.upload(h_next3, 3 * n);
+    uint8_t *d_p1 = sc.alloc<uint8_t>(plane), *d_n1 = sc.alloc<uint8_t>(plane), *d_s1 = sc.alloc<uint8_t>(plane);
+    float *d_flow = sc.alloc<float>(2 * n);
+    float *d_coarse = sc.alloc<float>(2 * OFX_MAX_LEVELS + 2); // 2 floats per level, then the shift vector
+    if (!sc.ok()) return sc.rc();
     float *d_uv = d_coarse + 2 * OFX_MAX_LEVELS;
-    hipError_t e = hipMemcpy(d_p3, h_prev3, 3 * n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d_n3, h_next3, 3 * n, hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        ofx_set_error("ofx_calc_opt_flow_host: upload: %s", hipGetErrorString(e));
-        return fail(OFX_E_HIP);
-    }
-    if ((rc = ofx_extract_ch0(d_p3, d_p1, w, h, pitch, nullptr)) != OFX_OK) return fail(rc);
-    if ((rc = ofx_extract_ch0(d_n3, d_n1, w, h, pitch, nullptr)) != OFX_OK) return fail(rc);
+    OFX_TRY(ofx_extract_ch0(d_p3, d_p1, w, h, pitch, nullptr));
+    OFX_TRY(ofx_extract_ch0(d_n3, d_n1, w, h, pitch, nullptr));
     ofx_geom g{w, h, pitch, 0, h, 0, h};
     const uint8_t *d_next = d_n1;
     if (level != max_level - 1) {
         float coarse[2 * OFX_MAX_LEVELS] = {};
         const float *lv[OFX_MAX_LEVELS] = {};
         for (int k = level + 1; k < max_level; ++k) {
-            if (!h_flow_pyr[k]) {
-                ofx_set_error("ofx_calc_opt_flow_host: flow level %d is null", k);
-                return fail(OFX_E_INVALID);
-            }
+            OFX_REQUIRE(h_flow_pyr[k] != nullptr, "ofx_calc_opt_flow_host: flow level %d is null", k);
             coarse[2 * k] = h_flow_pyr[k][0];
             coarse[2 * k + 1] = h_flow_pyr[k][1];
             lv[k] = d_coarse + 2 * k;
         }
-        e = hipMemcpy(d_coarse, coarse, sizeof coarse, hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
-            ofx_set_error("ofx_calc_opt_flow_host: upload: %s", hipGetErrorString(e));
-            return fail(OFX_E_HIP);
-        }
-        if ((rc = ofx_shift_vector(lv, level, max_level, d_uv, nullptr)) != OFX_OK) return fail(rc);
-        if ((rc = ofx_shift_1ch(d_n1, d_s1, &g, d_uv, nullptr)) != OFX_OK) return fail(rc);
+        OFX_HIP(hipMemcpy(d_coarse, coarse, sizeof coarse, hipMemcpyHostToDevice));
+        OFX_TRY(ofx_shift_vector(lv, level, max_level, d_uv, nullptr));
+        // (ofx_shift_1ch writes every pixel: shifted byte, own byte or the zero of the reference's fresh scratch pages)
+        OFX_TRY(ofx_shift_1ch(d_n1, d_s1, &g, d_uv, nullptr));
         d_next = d_s1;
     }
-    if ((rc = ofx_lk_level(d_p1, d_next, &g, window, mode, d_flow, 0, nullptr)) != OFX_OK) return fail(rc);
-    e = hipMemcpy(h_flow_pyr[level], d_flow, 2 * n * sizeof(float), hipMemcpyDeviceToHost);
-    if (e != hipSuccess) {
-        ofx_set_error("ofx_calc_opt_flow_host: download: %s", hipGetErrorString(e));
-        return fail(OFX_E_HIP);
+    OFX_TRY(ofx_lk_level(d_p1, d_next, &g, window, mode, d_flow, 0, nullptr));
+    sc.download(h_flow_pyr[level], d_flow, 2 * n);
+    return sc.rc();
+}
+
+
+// main.cu:138-147 with host pointers: the dense field at `level` that visualizeFlowField samples for its arrows --
+// sum over k >= level of 2^(k-level) * flow_k(y >> (k-level), x >> (k-level)) -- composed on the device.
+extern "C" int ofx_compose_flow_host(float *const *h_flow_pyr, int w, int h, int levels, int level, float *h_dst)
+{
+    OFX_REQUIRE(h_flow_pyr && h_dst && w > 0 && h > 0, "ofx_compose_flow_host: bad arguments");
+    OFX_REQUIRE(levels >= 1 && levels <= OFX_MAX_LEVELS && level >= 0 && level < levels, "ofx_compose_flow_host: bad level");
+    ofx_compat::Scratch sc;
+    const float *d_lv[OFX_MAX_LEVELS] = {};
+    for (int k = level; k < levels; ++k) {
+        OFX_REQUIRE(h_flow_pyr[k] != nullptr, "ofx_compose_flow_host: flow level %d is null", k);
+        // level k of a pyramid whose level `level` is w x h
+        d_lv[k] = sc.upload(h_flow_pyr[k], 2 * (size_t)(w >> (k - level)) * (size_t)(h >> (k - level)));
     }
-    OFX_HIP(hipFree(base));
-    return OFX_OK;
+    float *d_dst = sc.alloc<float>(2 * (size_t)w * (size_t)h);
+    if (sc.ok()) sc.run(ofx_compose_flow(d_lv, w, h, levels, level, d_dst, nullptr));
+    sc.download(h_dst, d_dst, 2 * (size_t)w * (size_t)h);
+    return sc.rc();
 }

@@ -72,6 +72,10 @@ _SIGS = {
     "ofx_solve_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "ofx_generate_gaussian_kernel": [_d, _i, _vp],
     "ofx_bilateral_3ch": [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _vp],
+    "ofx_sub_u8": [_vp, _vp, C.c_size_t, _vp, _vp],
+    "ofx_srm_3ch_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "ofx_downscale_mask_3ch": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "ofx_shift_3ch": [_vp, _vp, _i, _i, _vp, _vp],
     "ofx_session_create": [C.POINTER(Params), C.POINTER(_vp)],
     "ofx_session_destroy": [_vp],
     "ofx_session_set_frame_host": [_vp, _vp, _vp],
@@ -106,6 +110,7 @@ _SIGS = {
     "ofx_session_timing": [_vp, _i],
     "ofx_session_timing_read": [_vp, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)],
     "ofx_session_timing_read_kind": [_vp, _i, C.POINTER(_d), C.POINTER(_d), C.POINTER(_i)],
+    "ofx_compose_flow_host": [C.POINTER(_vp), _i, _i, _i, _i, _vp],
     "ofx_calc_opt_flow_host": [_vp, _vp, _i, _i, C.POINTER(_vp), _i, _i, _i, _i],
 }
 _RESTYPE = {"ofx_generate_gaussian_kernel": None}

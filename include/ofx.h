@@ -267,6 +267,18 @@ void ofx_generate_gaussian_kernel(double sigma_s, int kernel_size, double *h_dst
 int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int ww, int wh,
                       double sigma_s, double sigma_b, void *stream);
 
+/* the remaining functions of namespace cpu (OptFlowCpu.hpp:3-184), device-resident, so that the cpu:: call surface of
+ * include/OptFlowCpu.hpp runs on the MI355X as well */
+/* cpu::sub_arr, OptFlowCPU.cpp:11-17 (bytes, wrapping) */
+int ofx_sub_u8(const uint8_t *d_a, const uint8_t *d_b, size_t n, uint8_t *d_dst, void *stream);
+/* cpu::srm_3ch, OptFlowCPU.cpp:202-238 (bounds test `>` as there; taps past the end of the buffer contribute nothing) */
+int ofx_srm_3ch_u8(const uint8_t *d_a3, const uint8_t *d_b3, int w, int h, int ww, int wh, int32_t *d_dst3, void *stream);
+/* cpu::downscale_gaussian, OptFlowCPU.cpp:112-148: one pyramid level on 3ch images with the CALLER's mask (<= 81 taps) */
+int ofx_downscale_mask_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int dw, int dh, const float *h_mask, int mw, int mh, void *stream);
+/* cpu::shift_back_pyramid on the 3ch image, OptFlowCPU.cpp:241-282: d_dst3 keeps its contents except for its first w*h bytes
+ * (copied from d_src3) and the pixels whose shifted target lies inside the image */
+int ofx_shift_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int w, int h, const float *d_uv, void *stream);
+
 /* ---- session: device-resident pyramids for a stream of frames -------------
  * Mirrors main.cu:192-272: the previous frame's pyramid is kept, each new
  * frame gets its pyramid built and every level is solved coarse to fine. */
@@ -403,6 +415,10 @@ int ofx_session_timing_read_kind(ofx_session *s, int kind, double *avg_us, doubl
 /* gpu::calc_opt_flow (OptFlowGpu.cuh:33): host 3ch images in, host flow pyramid in/out. */
 int ofx_calc_opt_flow_host(const uint8_t *h_prev3, const uint8_t *h_next3, int w, int h, float **h_flow_pyr,
                            int level, int max_level, int window, int mode);
+
+/* main.cu:138-147 (the dense field visualizeFlowField samples) with host pointers: h_flow_pyr[k] for k >= level are the
+ * host flow levels gpu::calc_opt_flow filled, (w, h) is the size of `level`; h_dst receives 2*w*h floats. */
+int ofx_compose_flow_host(float *const *h_flow_pyr, int w, int h, int levels, int level, float *h_dst);
 
 #ifdef __cplusplus
 }

@@ -140,11 +140,41 @@ class Oracle:
         fn(_p(a, _f32p), _p(b, _f32p), w, h, ww, wh, _p(d, _f32p))
         return d
 
-    # ---- shift
-    def shift_back_pyramid(self, src3, level, max_level, flow_pyr):
+    def srm_3ch(self, a3, b3, ww, wh):
+        a3, b3 = _c(a3, np.uint8), _c(b3, np.uint8)
+        h, w, _ = a3.shape
+        d = np.empty((h, w, 3), np.int32)
+        self.lib.orc_srm_3ch(_p(a3, _u8p), _p(b3, _u8p), w, h, ww, wh, _p(d, _i32p))
+        return d
+
+    # ---- link-compat leftovers (utils::, gpu::conv_1d_3ch)
+    def cleanup_outliers(self, img1):
+        d = _c(img1, np.uint8).copy()
+        h, w = d.shape
+        self.lib.orc_cleanup_outliers(_p(d, _u8p), w, h)
+        return d
+
+    def upscale(self, src, n):
+        src = _c(src, np.uint8)
+        ch = 1 if src.ndim == 2 else src.shape[2]
+        h, w = src.shape[:2]
+        d = np.empty((h << n, w << n) + ((ch,) if src.ndim == 3 else ()), np.uint8)
+        self.lib.orc_upscale(_p(src, _u8p), w, h, n, ch, _p(d, _u8p))
+        return d
+
+    def conv_1d_3ch(self, src3):
         src3 = _c(src3, np.uint8)
         h, w, _ = src3.shape
-        d = np.zeros_like(src3)
+        d = np.empty_like(src3)
+        self.lib.orc_conv_1d_3ch(_p(src3, _u8p), w, h, _p(d, _u8p))
+        return d
+
+    # ---- shift
+    def shift_back_pyramid(self, src3, level, max_level, flow_pyr, dest_init=None):
+        """dest_init: what the caller's destination buffer holds before the call (default zeros)"""
+        src3 = _c(src3, np.uint8)
+        h, w, _ = src3.shape
+        d = np.zeros_like(src3) if dest_init is None else _c(dest_init, np.uint8).copy()
         fl = [_c(f, np.float32) if f is not None else np.zeros(2, np.float32) for f in flow_pyr]
         self.lib.orc_shift_back_pyramid(_p(src3, _u8p), w, h, level, max_level, _ptr_array(fl, C.c_float), _p(d, _u8p))
         return d
@@ -269,6 +299,7 @@ class Reference:
         self.lib = C.CDLL(REF_SO)
         for name in ("Dx_3x3", "Dy_3x3", "Dt_3x3", "GAUS_KERNEL_3x3"):
             setattr(self, name, np.array((C.c_float * 9).in_dll(self.lib, name), dtype=np.float32))
+        self.GAUS_KERNEL_5x5 = np.array((C.c_float * 25).in_dll(self.lib, "GAUS_KERNEL_5x5"), dtype=np.float32)
 
     def _f(self, mangled):
         f = getattr(self.lib, mangled)
@@ -311,13 +342,41 @@ class Reference:
         self._f("_ZN3cpu18downscale_gaussianEPhiiS0_PKfii")(_p(src3, _u8p), w, h, _p(d, _u8p), _p(mask, _f32p), mw, mh)
         return d
 
-    def gauss_pyramid(self, img3, levels):
+    def gauss_pyramid(self, img3, levels, mask=None, mw=3, mh=3):
         img3 = _c(img3, np.uint8)
+        mask = self.GAUS_KERNEL_3x3 if mask is None else _c(mask, np.float32)
         h, w, _ = img3.shape
         pyr = [img3.copy()] + [np.empty((h >> k, w >> k, 3), np.uint8) for k in range(1, levels)]
-        self._f("_ZN3cpu13gauss_pyramidEPPhiiiPKfii")(_ptr_array(pyr, C.c_uint8), w, h, levels,
-                                                      _p(self.GAUS_KERNEL_3x3, _f32p), 3, 3)
+        self._f("_ZN3cpu13gauss_pyramidEPPhiiiPKfii")(_ptr_array(pyr, C.c_uint8), w, h, levels, _p(mask, _f32p), mw, mh)
         return pyr
+
+    def srm_3ch(self, a3, b3, ww, wh):
+        """cpu::srm_3ch reads up to one row + one pixel past its inputs (bounds test `>`, OptFlowCPU.cpp:222): the inputs
+        are handed over inside larger zero-filled buffers, so that those reads are defined (and contribute nothing)."""
+        a3, b3 = _c(a3, np.uint8), _c(b3, np.uint8)
+        h, w, _ = a3.shape
+        pa, pb = np.zeros((h + 2, w, 3), np.uint8), np.zeros((h + 2, w, 3), np.uint8)
+        pa[:h], pb[:h] = a3, b3
+        d = np.empty((h, w, 3), np.int32)
+        self._f("_ZN3cpu7srm_3chEPhS0_iiiiPi")(_p(pa, _u8p), _p(pb, _u8p), w, h, ww, wh, _p(d, _i32p))
+        return d
+
+    def cleanup_outliers(self, img1):
+        d = _c(img1, np.uint8).copy()
+        h, w = d.shape
+        self._f("_ZN5utils16cleanup_outliersEPhii")(_p(d, _u8p), w, h)
+        return d
+
+    def upscale(self, src, n):
+        src = _c(src, np.uint8).copy()
+        h, w = src.shape[:2]
+        if src.ndim == 3:
+            d = np.empty((h << n, w << n, 3), np.uint8)
+            self._f("_ZN5utils11upscale_3chEPhiiiS0_")(_p(src, _u8p), w, h, n, _p(d, _u8p))
+        else:
+            d = np.empty((h << n, w << n), np.uint8)
+            self._f("_ZN5utils11upscale_1chEPhiiiS0_")(_p(src, _u8p), w, h, n, _p(d, _u8p))
+        return d
 
     def srm_1ch(self, a, b, ww, wh):
         a, b = _c(a, np.uint8), _c(b, np.uint8)
@@ -326,10 +385,10 @@ class Reference:
         self._f("_ZN3cpu7srm_1chEPKhS1_iiiiPi")(_p(a, _u8p), _p(b, _u8p), w, h, ww, wh, _p(d, _i32p))
         return d
 
-    def shift_back_pyramid(self, src3, level, max_level, flow_pyr):
+    def shift_back_pyramid(self, src3, level, max_level, flow_pyr, dest_init=None):
         src3 = _c(src3, np.uint8)
         h, w, _ = src3.shape
-        d = np.zeros_like(src3)
+        d = np.zeros_like(src3) if dest_init is None else _c(dest_init, np.uint8).copy()
         fl = [_c(f, np.float32) if f is not None else np.zeros(2, np.float32) for f in flow_pyr]
         self._f("_ZN3cpu18shift_back_pyramidEPKhiiiiPPfPh")(_p(src3, _u8p), w, h, level, max_level,
                                                            _ptr_array(fl, C.c_float), _p(d, _u8p))

@@ -597,3 +597,73 @@ void orc_lk_iter_level(const uint8_t *prev1, const uint8_t *next1_shifted, int w
     free(n3);
     free(p3);
 }
+
+/* ------------------------------------------------------------------------ */
+/* The rest of the reference's exported surface: link-compat functions the flow path does not use. */
+
+void orc_srm_3ch(const uint8_t *a3, const uint8_t *b3, int w, int h, int ww, int wh, int32_t *dst3)
+{
+    /* OptFlowCPU.cpp:202-238.  The window test is `cx < 0 || cy < 0 || cx > w || cy > h` (:222): column w and row h pass,
+     * so a tap one past the right edge lands on the first pixel of the next row (pos = cy*w + w) and a tap on row h reads
+     * past the image.  Positions inside the buffer (pos < w*h) are read exactly as the reference does; positions past its
+     * end -- undefined in the reference -- contribute nothing. */
+    const int ox = ww >> 1, oy = wh >> 1;
+    const size_t n = (size_t)w * (size_t)h;
+    for (int i = 0; i < h; ++i)
+        for (int j = 0; j < w; ++j) {
+            int acc[3] = {0, 0, 0};
+            for (int y = 0; y < wh; ++y) {
+                const int cy = i - oy + y;
+                if (cy < 0 || cy > h) continue;
+                for (int x = 0; x < ww; ++x) {
+                    const int cx = j - ox + x;
+                    if (cx < 0 || cx > w) continue;
+                    const size_t t = (size_t)cy * (size_t)w + (size_t)cx;
+                    if (t >= n) continue;
+                    acc[0] += (int)a3[3 * t] * (int)b3[3 * t];
+                    acc[1] += (int)a3[3 * t + 1] * (int)b3[3 * t + 1];
+                    acc[2] += (int)a3[3 * t + 2] * (int)b3[3 * t + 2];
+                }
+            }
+            int32_t *d = dst3 + 3 * ((size_t)i * w + j);
+            d[0] = acc[0];
+            d[1] = acc[1];
+            d[2] = acc[2];
+        }
+}
+
+void orc_cleanup_outliers(uint8_t *img1, int w, int h)
+{
+    /* OptFlowUtils.cpp:5-19: values in [20, 240) -> 255, the rest -> 0 */
+    const size_t n = (size_t)w * (size_t)h;
+    for (size_t p = 0; p < n; ++p) img1[p] = (img1[p] >= 240 || img1[p] < 20) ? 0 : 255;
+}
+
+void orc_upscale(const uint8_t *src, int w, int h, int n, int channels, uint8_t *dst)
+{
+    /* OptFlowUtils.cpp:21-61 (channels = 3 / 1): every source pixel becomes a 2^n x 2^n block */
+    const size_t ow = (size_t)w << n, oh = (size_t)h << n;
+    for (size_t oy = 0; oy < oh; ++oy)
+        for (size_t ox = 0; ox < ow; ++ox)
+            for (int c = 0; c < channels; ++c)
+                dst[channels * (oy * ow + ox) + c] = src[channels * ((oy >> n) * (size_t)w + (ox >> n)) + c];
+}
+
+void orc_conv_1d_3ch(const uint8_t *src3, int w, int h, uint8_t *dst3)
+{
+    /* OptFlowGpu.cu:1134-1189: 9 taps (0.1 .. 0.5 .. 0.1, :1164) along the PIXEL sequence, int accumulators that are
+     * truncated after every tap (`temp += (float)src * mask`, :1152-1154), result as unsigned char.  The reference passes
+     * the byte size as the element count (:1184), so its taps run up to 4 pixels past the end of the buffer; here taps
+     * outside [0, w*h) are skipped (the library's documented deviation, include/OptFlowGpu.cuh). */
+    static const float wgt[9] = {0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.4f, 0.3f, 0.2f, 0.1f};
+    const long npix = (long)w * (long)h;
+    for (long x = 0; x < npix; ++x) {
+        int acc[3] = {0, 0, 0};
+        for (int i = 0; i < 9; ++i) {
+            const long t = x - 4 + i;
+            if (t < 0 || t >= npix) continue;
+            for (int c = 0; c < 3; ++c) acc[c] = (int)((float)acc[c] + (float)src3[3 * t + c] * wgt[i]);
+        }
+        for (int c = 0; c < 3; ++c) dst3[3 * x + c] = (uint8_t)acc[c];
+    }
+}

@@ -133,6 +133,16 @@ void orc_lk_iter_level(const uint8_t *prev1, const uint8_t *next1_shifted, int w
 void orc_replicate_1ch_to_3ch(const uint8_t *src1, uint8_t *dst3, int n);
 void orc_extract_ch0(const uint8_t *src3, uint8_t *dst1, int n);
 
+/* link-compat leftovers */
+/* cpu::srm_3ch, OptFlowCPU.cpp:202-238 (positions past the end of the buffer contribute nothing) */
+void orc_srm_3ch(const uint8_t *a3, const uint8_t *b3, int w, int h, int ww, int wh, int32_t *dst3);
+/* utils::cleanup_outliers, OptFlowUtils.cpp:5-19 */
+void orc_cleanup_outliers(uint8_t *img1, int w, int h);
+/* utils::upscale_3ch / upscale_1ch, OptFlowUtils.cpp:21-61 */
+void orc_upscale(const uint8_t *src, int w, int h, int n, int channels, uint8_t *dst);
+/* gpu::conv_1d_3ch, OptFlowGpu.cu:1134-1189 (taps outside the buffer skipped) */
+void orc_conv_1d_3ch(const uint8_t *src3, int w, int h, uint8_t *dst3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,7 +100,39 @@ def bilateral():
          out_color_5=R.bilinear_filter_3ch(img, gray, 5, 5, 1.5, 20.0))
 
 
+def surface():
+    """The rest of the exported surface (SURVEY 8 f4 + the cpu:: twins whose arithmetic differs from the gpu:: ones)."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    img2 = rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)
+    d = {"img": img, "img2": img2, "mask5": R.GAUS_KERNEL_5x5}
+    for ww, wh in ((3, 3), (9, 9), (5, 7), (4, 4)):
+        d[f"srm3_{ww}x{wh}"] = R.srm_3ch(img, img2, ww, wh)
+    # cpu::gauss_pyramid honours its mask (gpu::gauss_pyramid does not): 5x5 Gaussian, 3 levels
+    pyr = R.gauss_pyramid(img, 3, R.GAUS_KERNEL_5x5, 5, 5)
+    d["pyr5_L1"], d["pyr5_L2"] = pyr[1], pyr[2]
+    d["down_dx"] = R.downscale_gaussian(img, R.Dx_3x3, 3, 3)          # negative / > 255 sums: float -> int -> byte
+    # shift with a destination buffer that is NOT zero: pixels whose target leaves the image keep the caller's bytes
+    dest0 = rng.integers(0, 256, img.shape, dtype=np.uint8)
+    d["shift_dest0"] = dest0
+    cases = [(2.5, -1.25), (-40.0, 3.0), (float("nan"), 0.0), (0.0, 0.0)]
+    d["shift_uv"] = np.array(cases, np.float32)
+    for i, (u, v) in enumerate(cases):
+        f1 = np.array([[[u / 2, v / 2]]], np.float32)
+        d[f"shift3_{i}"] = R.shift_back_pyramid(img, 0, 2, [None, f1], dest_init=dest0)
+    g1 = rng.integers(0, 256, (10, 14), dtype=np.uint8)
+    d["g1"] = g1
+    d["cleanup"] = R.cleanup_outliers(g1)
+    for n in (0, 1, 2):
+        d[f"up1_{n}"] = R.upscale(g1, n)
+        d[f"up3_{n}"] = R.upscale(img[:6, :5], n)
+    save("surface", **d)
+
+
 if __name__ == "__main__":
+    surface()
+    if "--only-surface" in sys.argv:
+        sys.exit(0)
     primitives()
     shifts()
     levels_and_pairs()

@@ -48,9 +48,111 @@ def test_reference_cpp_surface_is_exported(exported):
     from cuda_optical_flow_2_amd import compat
 
     want = set(compat.GPU_SYMBOLS.values()) | set(compat.UTILS_SYMBOLS.values()) | set(compat.MASK_SYMBOLS)
+    want |= set(compat.CPU_SYMBOLS.values())   # the 12 functions of OptFlowCpu.hpp
+    assert len(compat.CPU_SYMBOLS) == 12 and len(compat.GPU_SYMBOLS) == 16
     missing = sorted(want - exported)
     assert not missing, missing
     assert "gpu_compat_last_status" in exported
+
+
+def test_mangled_names_follow_from_the_headers(exported):
+    """The names in compat.py are not hand-copied strings the library merely agrees with: compile the declarations of
+    include/OptFlowCpu.hpp / OptFlowGpu.cuh / OptFlowUtils.hpp into references and let the C++ compiler mangle them."""
+    import tempfile
+
+    from cuda_optical_flow_2_amd import compat
+
+    src = '#include "OptFlowCpu.hpp"\n#include "OptFlowGpu.cuh"\n#include "OptFlowUtils.hpp"\n#include "kernels.hpp"\nvoid *refs[] = {\n'
+    for ns, table in (("cpu", compat.CPU_SYMBOLS), ("gpu", compat.GPU_SYMBOLS), ("utils", compat.UTILS_SYMBOLS)):
+        src += "".join(f"  (void *)&{ns}::{name},\n" for name in table)
+    src += "".join(f"  (void *)&{m},\n" for m in compat.MASK_SYMBOLS) + "};\n"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "refs.cpp")
+        open(c, "w").write(src)
+        o = os.path.join(d, "refs.o")
+        subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-c", c, "-o", o], check=True)
+        out = subprocess.run(["nm", "-u", o], capture_output=True, text=True, check=True).stdout
+    undefined = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    want = set(compat.CPU_SYMBOLS.values()) | set(compat.GPU_SYMBOLS.values()) | set(compat.UTILS_SYMBOLS.values()) | set(compat.MASK_SYMBOLS)
+    assert want <= undefined, sorted(want - undefined)
+    assert want <= exported
+
+
+def test_main_cu_include_block_and_call_sites_compile_against_include_dir():
+    """main.cu:1-15 (its include block, verbatim lines) and its call sites of the library (main.cu:46-87,128,198-262) must
+    compile against this repo's include/ WITHOUT an edit: the two CUDA headers resolve to the empty files in include/, the
+    cpu:: / gpu:: / utils:: calls and the mask tables to the reference-shaped headers.  OpenCV is not in this image, so the
+    three opencv2 headers are stubbed HERE, in the test (never in include/), with the handful of cv:: members those call
+    sites touch.  The translation unit below restates the call sites' shapes; it is not a copy of main.cu."""
+    import tempfile
+
+    stub_core = """
+#pragma once
+namespace cv { struct Mat { unsigned char *data; int rows, cols; Mat() : data(nullptr), rows(0), cols(0) {} }; }
+"""
+    tu = """
+#include "kernels.hpp"
+#include "OptFlowCpu.hpp"
+#include "OptFlowUtils.hpp"
+
+#include <stdio.h>
+#include <cuda_runtime.h>
+#include <device_launch_parameters.h>
+#include <stdlib.h>
+
+#include <opencv2/core.hpp>
+#include <opencv2/imgproc/imgproc.hpp>
+#include <opencv2/highgui/highgui.hpp>
+#include "main.h"
+
+#include "OptFlowGpu.cuh"
+
+using namespace std;
+
+void call_sites(cv::Mat src, cv::Mat gray, cv::Mat filtered, unsigned char **pyramid, unsigned char **prev_pyramid,
+                float **flow_pyramid, unsigned char *t1, unsigned char *t2, cv::Mat scaled, int levels)
+{
+    int w = src.cols, h = src.rows, k = 1;
+    gpu::conv_3ch_1ch_tiled(pyramid[k], w, h, t1, Dx_3x3, 3, 3);
+    utils::cleanup_outliers(t1, w, h);
+    utils::upscale_1ch(t1, w, h, k, scaled.data);
+    utils::upscale_3ch(pyramid[k], w, h, k, scaled.data);
+    gpu::conv_3ch_1ch_tiled(pyramid[k], w, h, t2, Dt_3x3_n, 3, 3);
+    gpu::conv_3ch_1ch_tiled(prev_pyramid[k], w, h, t1, Dt_3x3_n, 3, 3);
+    cpu::sub_arr(t2, t1, w * h, t1);
+    gpu::conv_3ch_1ch_tiled(pyramid[k], w, h, t1, Dy_3x3, 3, 3);
+    gpu::grayscale_avg(src.data, gray.data, src.rows, src.cols);
+    cpu::grayscale_avg_cpu(src.data, gray.data, src.rows, src.cols);
+    gpu::gauss_pyramid(prev_pyramid, gray.cols, gray.rows, levels, GAUS_KERNEL_3x3, 3, 3);
+    cpu::bilinear_filter_3ch(gray.data, gray.data, filtered.data, w, h, 9, 9, 10, 20);
+    gpu::bilinear_filter(gray.data, gray.data, filtered.data, w, h, 9, 9, 2, 10);
+    gpu::gauss_pyramid(pyramid, src.cols, src.rows, levels, GAUS_KERNEL_3x3, 3, 3);
+    cpu::gauss_pyramid(pyramid, src.cols, src.rows, levels, GAUS_KERNEL_3x3, 3, 3);
+    for (k = levels - 1; k >= 0; k--) {
+        int tmp_w = w >> k, tmp_h = h >> k;
+        gpu::calc_opt_flow(prev_pyramid[k], pyramid[k], tmp_w, tmp_h, flow_pyramid, k, levels);
+        cpu::calc_optical_flow(prev_pyramid[k], pyramid[k], tmp_w, tmp_h, flow_pyramid, k, levels);
+    }
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "opencv2", "imgproc"))
+        os.makedirs(os.path.join(d, "opencv2", "highgui"))
+        open(os.path.join(d, "opencv2", "core.hpp"), "w").write(stub_core)
+        open(os.path.join(d, "opencv2", "imgproc", "imgproc.hpp"), "w").write("#pragma once\n")
+        open(os.path.join(d, "opencv2", "highgui", "highgui.hpp"), "w").write("#pragma once\n")
+        c = os.path.join(d, "main_shape.cpp")
+        open(c, "w").write(tu)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-I", d, c], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        # and the same translation unit LINKS against the library (every symbol it calls is exported)
+        from cuda_optical_flow_2_amd import lib
+
+        o = os.path.join(d, "main_shape.o")
+        subprocess.run(["g++", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"), "-I", d, "-c", c, "-o", o], check=True)
+        r = subprocess.run(["g++", "-shared", "-o", os.path.join(d, "main_shape.so"), o, "-Wl,--no-undefined", "-L" + lib.PKG, "-lofx_hip",
+                            "-Wl,--allow-shlib-undefined"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_struct_layout_matches_header():

@@ -1,0 +1,193 @@
+"""GPU: the whole exported C++ surface through its mangled names -- namespace cpu (include/OptFlowCpu.hpp), namespace utils
+and the gpu:: leftovers -- against the goldens generated from the reference's own CPU build (tests/golden/) and the oracle.
+The cpu:: functions are the reference's CPU call surface executed on the device (csrc/compat_cpu.cpp), so every one of
+them is held to the reference's bits."""
+import numpy as np
+import pytest
+
+from conftest import assert_same
+from cuda_optical_flow_2_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cpu():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cuda_optical_flow_2_amd.compat import CpuCompat
+
+    return CpuCompat()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from cuda_optical_flow_2_amd.compat import GpuCompat
+
+    return GpuCompat()
+
+
+@pytest.fixture(scope="module")
+def utils():
+    from cuda_optical_flow_2_amd.compat import UtilsCompat
+
+    return UtilsCompat()
+
+
+def test_cpu_namespace_primitives_golden(cpu, gpu, golden):
+    g = golden("primitives")
+    img, gray = g["img"], g["gray"]
+    assert_same(cpu.grayscale_avg_cpu(img), gray, "cpu::grayscale_avg_cpu")
+    for nm, m in (("dx", gpu.Dx_3x3), ("dy", gpu.Dy_3x3), ("dt", gpu.Dt_3x3), ("gaus", gpu.GAUS_KERNEL_3x3)):
+        assert_same(cpu.conv_3ch_to_1ch(gray, m), g["conv1_" + nm], f"cpu::conv_3ch_to_1ch {nm}")
+        assert_same(cpu.conv_3ch(img, m, 3, 3), g["conv3_" + nm], f"cpu::conv_3ch {nm}")
+    assert_same(cpu.conv_3ch_to_1ch(gray, g["mask5"], 5, 5), g["conv1_m5"], "cpu::conv_3ch_to_1ch 5x5")
+    assert_same(cpu.conv_3ch(img, g["mask5"], 5, 5), g["conv3_m5"], "cpu::conv_3ch 5x5")
+    assert_same(cpu.downscale_gaussian(img, gpu.GAUS_KERNEL_3x3), g["down"], "cpu::downscale_gaussian")
+    assert_same(cpu.sub_arr(g["a"], g["b"]), g["sub"], "cpu::sub_arr (main.cu:64)")
+    for ww, wh in ((3, 3), (5, 5), (7, 7), (9, 9), (15, 15), (19, 19), (5, 9), (4, 6)):
+        assert_same(cpu.srm_1ch(g["a"], g["b"], ww, wh), g[f"srm_{ww}x{wh}"], f"cpu::srm_1ch {ww}x{wh}")
+    assert_same(cpu.inverse_matrix(*g["solve_in"]), g["solve_f32arith"], "cpu::inverse_matrix (float arithmetic)")
+
+
+def test_cpu_namespace_surface_golden(cpu, golden):
+    g = golden("surface")
+    img, img2 = g["img"], g["img2"]
+    for ww, wh in ((3, 3), (9, 9), (5, 7), (4, 4)):
+        assert_same(cpu.srm_3ch(img, img2, ww, wh), g[f"srm3_{ww}x{wh}"], f"cpu::srm_3ch {ww}x{wh}")
+    pyr = cpu.gauss_pyramid(img, 3, g["mask5"], 5, 5)   # cpu::gauss_pyramid honours its mask
+    assert_same(pyr[1], g["pyr5_L1"], "cpu::gauss_pyramid 5x5 L1")
+    assert_same(pyr[2], g["pyr5_L2"], "cpu::gauss_pyramid 5x5 L2")
+    dx = np.array([-1, 0, 1, -2, 0, 2, -1, 0, 1], np.float32)
+    assert_same(cpu.downscale_gaussian(img, dx), g["down_dx"], "cpu::downscale_gaussian with a signed mask")
+    for i, (u, v) in enumerate(g["shift_uv"]):
+        f1 = np.array([[[u / 2, v / 2]]], np.float32)
+        assert_same(cpu.shift_back_pyramid(img, 0, 2, [None, f1], dest_init=g["shift_dest0"]), g[f"shift3_{i}"],
+                    f"cpu::shift_back_pyramid case {i} into a dirty destination")
+
+
+def test_cpu_shift_golden(cpu, golden):
+    g = golden("shift")
+    for i in range(len(g["uv"])):
+        got = cpu.shift_back_pyramid(g["img"], 0, 3, [None, g[f"f1_{i}"], g[f"f2_{i}"]])
+        assert_same(got, g[f"shift_{i}"], f"cpu::shift_back_pyramid case {i} uv={g['uv'][i]}")
+
+
+def test_cpu_calc_optical_flow_golden(cpu, gpu, golden):
+    """cpu::calc_optical_flow == the reference's own CPU output: single levels and the 3-level pipeline of main.cu:256-262
+    with the cpu:: alternates swapped in (main.cu:251,261)."""
+    g = golden("levels")
+    for tag in ("smooth", "random"):
+        p3, n3 = synth.to_3ch(g[tag + "_prev"]), synth.to_3ch(g[tag + "_next"])
+        flow = [np.zeros((48, 64, 2), np.float32)]
+        cpu.calc_optical_flow(p3, n3, flow, 0, 1)
+        assert_same(flow[0], g[tag + "_flow_single"], "cpu::calc_optical_flow single level " + tag)
+    fl, pp, npyr = cpu.flow_pair(synth.to_3ch(g["pair_prev"]), synth.to_3ch(g["pair_next"]), 3, gpu.GAUS_KERNEL_3x3)
+    for k in range(3):
+        assert_same(pp[k][:, :, 0], g[f"pair_prevpyr_L{k}"], f"prev pyramid L{k}")
+        assert_same(npyr[k][:, :, 0], g[f"pair_nextpyr_L{k}"], f"next pyramid L{k}")
+        assert_same(fl[k], g[f"pair_flow_L{k}"], f"cpu:: 3-level pipeline flow L{k}")
+
+
+def test_cpu_bilinear_filter_golden(cpu, golden):
+    g = golden("bilateral")
+    assert_same(cpu.bilinear_filter_3ch(g["gray"], g["gray"], 9, 9, 2.0, 10.0), g["out_gray_9"], "cpu::bilinear_filter_3ch 9x9 (main.cu:239)")
+    assert_same(cpu.bilinear_filter_3ch(g["img"], g["gray"], 5, 5, 1.5, 20.0), g["out_color_5"], "cpu::bilinear_filter_3ch 5x5")
+
+
+def test_cpu_namespace_larger_inputs_vs_oracle(cpu, oracle):
+    """sizes that span several blocks and odd extents, against the oracle (itself pinned to the reference build)"""
+    rng = np.random.default_rng(23)
+    a = rng.integers(0, 256, (67, 301, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (67, 301, 3), dtype=np.uint8)
+    assert_same(cpu.srm_3ch(a, b, 9, 9), oracle.srm_3ch(a, b, 9, 9), "cpu::srm_3ch 301x67")
+    assert_same(cpu.srm_3ch(a, b, 2, 6), oracle.srm_3ch(a, b, 2, 6), "cpu::srm_3ch even window")
+    big = rng.integers(0, 256, (128, 520, 3), dtype=np.uint8)
+    m = rng.normal(size=25).astype(np.float32)
+    for x, y in zip(cpu.gauss_pyramid(big, 4, m, 5, 5), oracle.gauss_pyramid(big, 4, m, 5, 5)):
+        assert_same(x, y, "cpu::gauss_pyramid arbitrary 5x5 mask")
+    dirty = rng.integers(0, 256, big.shape, dtype=np.uint8)
+    for uv in ((2.5, -1.25), (-519.0, 3.0), (float("nan"), 0.0), (1e20, 0.0), (0.0, 127.5), (-0.999, -0.999)):
+        fl = [None, np.array([[[uv[0] / 2, uv[1] / 2]]], np.float32)]
+        assert_same(cpu.shift_back_pyramid(big, 0, 2, fl, dest_init=dirty), oracle.shift_back_pyramid(big, 0, 2, fl, dest_init=dirty), f"shift {uv}")
+    x = rng.integers(0, 256, (40, 1000), dtype=np.uint8)
+    y = rng.integers(0, 256, (40, 1000), dtype=np.uint8)
+    assert_same(cpu.sub_arr(x, y), oracle.sub_u8(x, y), "cpu::sub_arr")
+
+
+def test_utils_namespace_golden(utils, golden, oracle):
+    g = golden("surface")
+    assert_same(utils.cleanup_outliers(g["g1"]), g["cleanup"], "utils::cleanup_outliers")
+    for n in (0, 1, 2):
+        assert_same(utils.upscale(g["g1"], n), g[f"up1_{n}"], f"utils::upscale_1ch n={n}")
+        assert_same(utils.upscale(g["img"][:6, :5], n), g[f"up3_{n}"], f"utils::upscale_3ch n={n}")
+    b = golden("bilateral")
+    assert_same(utils.generate_gaussian_kernel(2.0, 9), b["gk_9_2"], "utils::generate_gaussian_kernel")
+    assert_same(utils.generate_gaussian_kernel(1.5, 5), b["gk_5_1p5"], "utils::generate_gaussian_kernel")
+
+
+def test_gpu_conv_1d_3ch_matches_restatement(gpu, oracle):
+    """gpu::conv_1d_3ch (the reference's practice kernel, OptFlowGpu.cu:1134-1189) vs its restatement; taps past the end of
+    the buffer -- which the reference reads -- are skipped by both (documented deviation)."""
+    rng = np.random.default_rng(4)
+    for (h, w) in ((7, 9), (33, 130), (1, 5)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        assert_same(gpu.conv_1d_3ch(img), oracle.conv_1d_3ch(img), f"gpu::conv_1d_3ch {w}x{h}")
+
+
+def test_wrappers_do_not_allocate_in_the_steady_state(gpu):
+    """The host-pointer wrappers carve their device buffers out of a cached per-thread arena (compat_scratch.h): after the
+    first call of a given size, repeating it must leave the device's free memory unchanged."""
+    import torch
+
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)
+    gpu.grayscale_avg(img)
+    gpu.gauss_pyramid(img, 4)
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        gpu.grayscale_avg(img)
+        gpu.gauss_pyramid(img, 4)
+        assert torch.cuda.mem_get_info()[0] == free0
+
+
+def test_replay_of_main_cu_frame_loop(oracle, tmp_path):
+    """examples/replay_main.cpp -- main.cu:192-272's call sequence through the gpu:: symbols, linked against libofx_hip.so
+    by __graft_entry__.build() -- run as a program on three raw frames: the composed level-0 field it writes (main.cu:138-147
+    via ofx_compose_flow_host) must equal the oracle's restatement of that loop: grayscale -> bilateral 9x9 (2, 10) ->
+    pyramid -> calc_opt_flow (window 19, Dt_3x3) per level -> composition."""
+    import os
+    import subprocess
+
+    from cuda_optical_flow_2_amd import build as hip_build, lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "replay_main")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(exe + ".cpp"):
+        subprocess.check_call([hip_build.hipcc(), "-std=c++17", "-I" + os.path.join(root, "include"), exe + ".cpp", "-L" + lib.PKG, "-lofx_hip",
+                               "-Wl,-rpath," + lib.PKG, "-o", exe])
+    w, h, levels, nf = 320, 240, 4, 3
+    rng = np.random.default_rng(8)
+    frames = []
+    for i in range(nf + 1):
+        g = synth.smooth_pair(w, h, 1.5 * i, -0.75 * i, seed=77)[1].astype(np.int32)
+        # a colour image whose channel mean is not any single channel (exercises grayscale_avg)
+        f = np.stack([np.clip(g + 9, 0, 255), np.clip(g - 7, 0, 255), g], axis=2).astype(np.uint8)
+        frames.append(f)
+    raw, fld = tmp_path / "frames.raw", tmp_path / "field.raw"
+    raw.write_bytes(b"".join(f.tobytes() for f in frames))
+    r = subprocess.run([exe, str(w), str(h), str(nf), str(raw), str(fld)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.fromfile(fld, np.float32).reshape(nf, h, w, 2)
+
+    prev_pyr = oracle.gauss_pyramid(oracle.grayscale_avg(frames[0]), levels)          # main.cu:198-209: the first frame is not filtered
+    for f in range(1, nf + 1):
+        gray = oracle.grayscale_avg(frames[f])
+        pyr = oracle.gauss_pyramid(oracle.bilateral_3ch(gray, gray, 9, 9, 2.0, 10.0), levels)
+        flow = [np.zeros((h >> k, w >> k, 2), np.float32) for k in range(levels)]
+        for k in range(levels - 1, -1, -1):
+            oracle.calc_opt_flow_gpu(prev_pyr[k], pyr[k], flow, k, levels, 19, exact_sums=True)
+        assert_same(got[f - 1], oracle.compose_flow(flow, levels, 0), f"replay frame {f}: composed level-0 field")
+        prev_pyr = pyr
+    assert r.stdout.count("fnv") == nf

@@ -51,6 +51,26 @@ def test_bilateral_golden(oracle, golden):
     assert_same(oracle.bilateral_3ch(g["img"], g["gray"], 5, 5, 1.5, 20.0), g["out_color_5"], "bilateral colour 5x5")
 
 
+def test_surface_golden(oracle, golden):
+    """The rest of the exported surface (cpu::srm_3ch, cpu::gauss_pyramid with a caller's mask, the 3-channel shift into a
+    non-zero destination, utils::cleanup_outliers / upscale_*): oracle restatement == the reference's own build."""
+    g = golden("surface")
+    img, img2 = g["img"], g["img2"]
+    for ww, wh in ((3, 3), (9, 9), (5, 7), (4, 4)):
+        assert_same(oracle.srm_3ch(img, img2, ww, wh), g[f"srm3_{ww}x{wh}"], f"srm_3ch {ww}x{wh}")
+    pyr = oracle.gauss_pyramid(img, 3, g["mask5"], 5, 5)
+    assert_same(pyr[1], g["pyr5_L1"], "5x5 pyramid L1")
+    assert_same(pyr[2], g["pyr5_L2"], "5x5 pyramid L2")
+    assert_same(oracle.downscale_gaussian(img, oracle.Dx_3x3, 3, 3), g["down_dx"], "downscale with a signed mask")
+    for i, (u, v) in enumerate(g["shift_uv"]):
+        f1 = np.array([[[u / 2, v / 2]]], np.float32)
+        assert_same(oracle.shift_back_pyramid(img, 0, 2, [None, f1], dest_init=g["shift_dest0"]), g[f"shift3_{i}"], f"3ch shift {i}")
+    assert_same(oracle.cleanup_outliers(g["g1"]), g["cleanup"], "cleanup_outliers")
+    for n in (0, 1, 2):
+        assert_same(oracle.upscale(g["g1"], n), g[f"up1_{n}"], f"upscale_1ch {n}")
+        assert_same(oracle.upscale(img[:6, :5], n), g[f"up3_{n}"], f"upscale_3ch {n}")
+
+
 # ---- known-answer vectors of SURVEY.md 8c(iv), verified there against the reference build -------------------------
 
 def test_kat_gaussian_truncation(oracle):

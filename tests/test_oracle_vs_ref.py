@@ -61,3 +61,26 @@ def test_bilateral(oracle, ref):
     assert_same(oracle.generate_gaussian_kernel(2.0, 9), ref.generate_gaussian_kernel(2.0, 9), "gaussian kernel")
     assert_same(oracle.bilateral_3ch(gs, gs, 9, 9, 2, 10), ref.bilinear_filter_3ch(gs, gs, 9, 9, 2, 10), "bilateral grey")
     assert_same(oracle.bilateral_3ch(img, gs, 5, 5, 1.5, 20), ref.bilinear_filter_3ch(img, gs, 5, 5, 1.5, 20), "bilateral colour")
+
+
+def test_leftover_surface(oracle, ref):
+    """cpu::srm_3ch (its `>` bounds test), cpu::gauss_pyramid with arbitrary masks, the 3-channel shift into a dirty
+    destination, utils::cleanup_outliers / upscale_*."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (21, 34, 3), dtype=np.uint8)
+    b = rng.integers(0, 256, (21, 34, 3), dtype=np.uint8)
+    for ww, wh in ((3, 3), (9, 9), (7, 5), (2, 6), (1, 1), (35, 3)):
+        assert_same(oracle.srm_3ch(a, b, ww, wh), ref.srm_3ch(a, b, ww, wh), f"srm_3ch {ww}x{wh}")
+    big = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    for mask, mw, mh in ((ref.GAUS_KERNEL_5x5, 5, 5), (rng.normal(size=9).astype(np.float32), 3, 3), (np.full(12, 0.1, np.float32), 4, 3)):
+        for x, y in zip(oracle.gauss_pyramid(big, 3, mask, mw, mh), ref.gauss_pyramid(big, 3, mask, mw, mh)):
+            assert_same(x, y, f"pyramid with a {mw}x{mh} mask")
+    dirty = rng.integers(0, 256, big.shape, dtype=np.uint8)
+    for uv in ((2.5, -1.25), (-70.0, 3.0), (np.nan, 0.0), (0.0, 0.0), (0.0, 47.9)):
+        fl = [None, np.array([[[uv[0] / 2, uv[1] / 2]]], np.float32)]
+        assert_same(oracle.shift_back_pyramid(big, 0, 2, fl, dest_init=dirty), ref.shift_back_pyramid(big, 0, 2, fl, dest_init=dirty), f"shift {uv}")
+    g1 = rng.integers(0, 256, (9, 13), dtype=np.uint8)
+    assert_same(oracle.cleanup_outliers(g1), ref.cleanup_outliers(g1), "cleanup_outliers")
+    for n in (0, 1, 3):
+        assert_same(oracle.upscale(g1, n), ref.upscale(g1, n), f"upscale_1ch {n}")
+        assert_same(oracle.upscale(a[:5, :7], n), ref.upscale(a[:5, :7], n), f"upscale_3ch {n}")
