@@ -139,7 +139,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=104)
     ap.add_argument("--workload", default="4k", choices=sorted(WORKLOADS))
-    ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu"])
+    ap.add_argument("--mode", default="lk_float", choices=["lk_float", "compat_cpu", "lk_float_fast"],
+                    help="lk_float: gpu::calc_opt_flow's arithmetic with the solve replayed bit for bit (default); lk_float_fast: the same with "
+                         "the solve in its <= 1 ulp formulation (OFX_MODE_LK_FLOAT_FAST); compat_cpu: cpu::calc_optical_flow bug for bug")
     ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
                     help="single-GPU execution path: stream pipeline (default), two-stream staged pairs, or the plain sequence")
     ap.add_argument("--iters", type=int, default=1,
@@ -652,6 +654,11 @@ def main():
                     extra["cold_inputs"] = r6
                     del cold_ring
             if args.path == "stream":
+                # the same pipeline with the solve in its <= 1 ulp(float) formulation (OFX_MODE_LK_FLOAT_FAST: SURVEY 8c's stated
+                # tolerance for the solve, identical NaN / Inf positions; window sums, shift and pyramid stay bit-exact)
+                r8 = stream_leg((w, h, levels, window), "lk_float_fast", args.batch, args.borrow, d_ring, args.steps)
+                r8["workload"] = "as value, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
+                extra["fast_solve"] = r8
                 # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
                 bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow)
                 r7 = stream_leg((w, h, levels, window), "compat_cpu", bc, args.borrow, d_ring if bc == args.batch else make_ring(d_frames, ring_size(bc)), args.steps)

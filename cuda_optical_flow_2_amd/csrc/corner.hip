@@ -13,12 +13,12 @@ using namespace ofx_dev;
 
 namespace {
 
-template <int MODE>
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
 {
     __shared__ float f0[2 * OFX_MAX_LEVELS];
     __shared__ __attribute__((aligned(16))) uint8_t cache[kCornerTileBytes + OFX_MAX_LEVELS * kCornerCacheBytes];
-    corner_wave<MODE>(A, (int)threadIdx.x, f0, cache);
+    corner_wave<MODE, FAST>(A, (int)threadIdx.x, f0, cache);
 }
 
 // Row-sharded sessions that RECEIVE their shift vectors (rank 0's corner kernel + broadcast) check them here: the level
@@ -70,9 +70,10 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
     OFX_REQUIRE(levels && d_uv && n_levels >= 1 && n_levels <= OFX_MAX_LEVELS, "ofx_corner_flows: bad arguments");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_corner_flows: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE((window >> 1) <= kCornerMaxRadius, "ofx_corner_flows: window %d not supported (at most %d)", window, 2 * kCornerMaxRadius + 1);
-    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_corner_flows: bad mode %d", mode);
+    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT || mode == OFX_MODE_LK_FLOAT_FAST, "ofx_corner_flows: bad mode %d", mode);
     CornerArgs a{};
     a.levels = n_levels;
+    a.min_det = levels[0].min_det;
     a.radius = window >> 1;
     a.uv = d_uv;
     a.status = d_status;
@@ -101,9 +102,11 @@ extern "C" int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int win
     CornerArgs a{};
     OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, nullptr, &a));
     if (mode == OFX_MODE_LK_FLOAT)
-        hipLaunchKernelGGL(corner_kernel<OFX_MODE_LK_FLOAT>, dim3(1), dim3(64), 0, ofx_stream(stream), a);
+        hipLaunchKernelGGL((corner_kernel<OFX_MODE_LK_FLOAT, false>), dim3(1), dim3(64), 0, ofx_stream(stream), a);
+    else if (mode == OFX_MODE_LK_FLOAT_FAST)
+        hipLaunchKernelGGL((corner_kernel<OFX_MODE_LK_FLOAT, true>), dim3(1), dim3(64), 0, ofx_stream(stream), a);
     else
-        hipLaunchKernelGGL(corner_kernel<OFX_MODE_COMPAT_CPU>, dim3(1), dim3(64), 0, ofx_stream(stream), a);
+        hipLaunchKernelGGL((corner_kernel<OFX_MODE_COMPAT_CPU, false>), dim3(1), dim3(64), 0, ofx_stream(stream), a);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }

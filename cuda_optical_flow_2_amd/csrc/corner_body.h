@@ -23,6 +23,7 @@ struct CornerArgs {
     int *status; // optional: bit k is set when level k needed a pixel inside the image but outside its planes, bit 8 + k
                  // when level k's vertical shift sends the shard's reads to image rows its buffers do not hold
     int levels, radius;
+    float min_det; // determinant guard of the solve (lk_solve.h), as the level kernel of the same pair applies it
 };
 
 // The chain's pixels come from LDS: before the walk, the wave copies the top-left corner of every level -- 16 x 16 bytes of
@@ -121,7 +122,7 @@ __device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, u
 // found so far) and cache = kCornerTileBytes + levels * kCornerCacheBytes bytes (two resolved tiles, then corner_prefetch's
 // corners).  Only wave-level ordering is needed, so the
 // function can run inside a larger workgroup.
-template <int MODE>
+template <int MODE, bool FAST = false>
 __device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float *f0, uint8_t *cache)
 {
     uint8_t *tileP = cache, *tileQ = cache + kCornerPrevDim * kCornerPrevDim;
@@ -213,7 +214,7 @@ __device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float
             syt += __shfl_xor(syt, m);
         }
         float fu, fv;
-        solve2x2<MODE>(sxx, syy, sxy, sxt, syt, fu, fv);
+        solve2x2<MODE, FAST>(sxx, syy, sxy, sxt, syt, SolveOpts{A.min_det}, fu, fv); // every lane holds the same sums
         if (A.status != nullptr && __any(miss != 0) && lane == 0) atomicOr(A.status, 1 << k);
         if (lane == 0) {
             f0[2 * k] = fu;

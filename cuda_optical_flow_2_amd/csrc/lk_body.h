@@ -20,6 +20,7 @@ struct LkArgs {
     int out_y0, out_y1, flow_row0;
     int strip_h, tiles_x;
     int accumulate; // non-zero: flow += result (refinement iterations) instead of flow = result
+    float min_det;  // > 0: determinant guard of the solve (lk_solve.h); <= 0: the reference
 };
 
 // one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
@@ -552,7 +553,8 @@ __device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&i
 // One wave of the fused level kernel: `wave` indexes the (level, tile, strip) work items of the table, `lane` is 0..63.
 // MAY_ACC: the launch may contain accumulating items (refinement iterations); false compiles that path out (the stream
 // kernel never has any, and the extra live registers would push it over its 96-VGPR budget)
-template <int R, int MODE, bool SUMS, bool MAY_ACC = true>
+// FAST: the <= 1 ulp solve (lk_solve.h) instead of the replay of the reference's operation order
+template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false>
 __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 {
     using G = TileGeom<R>;
@@ -579,6 +581,8 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     pin_scalar(A.row_end);
     pin_scalar(A.flow_row0);
     pin_scalar(A.accumulate);
+    pin_scalar(A.min_det);
+    const SolveOpts sopt{A.min_det};
     if constexpr (SUMS) {
         pin_scalar(A.sums);
         pin_scalar(A.sums_plane);
@@ -859,7 +863,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
             if constexpr (!SUMS) {
                 // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
 #pragma unroll
-                for (int j = 0; j < 4; ++j) solve2x2<MODE>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], uv[2 * j], uv[2 * j + 1]);
+                for (int j = 0; j < 4; ++j) solve2x2<MODE, FAST>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], sopt, uv[2 * j], uv[2 * j + 1]);
             }
         }
         take_rows();

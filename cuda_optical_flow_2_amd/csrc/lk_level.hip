@@ -34,10 +34,10 @@ namespace {
 #ifndef OFX_LK_MIN_WAVES
 #define OFX_LK_MIN_WAVES(R) 3 // A/B on MI355X: capping at 128 VGPRs (4 waves) spills in the marching loop and is slower
 #endif
-template <int R, int MODE, bool SUMS>
+template <int R, int MODE, bool SUMS, bool FAST>
 __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const LkTable T)
 {
-    lk_wave<R, MODE, SUMS>(T, (int)blockIdx.x, (int)threadIdx.x);
+    lk_wave<R, MODE, SUMS, true, FAST>(T, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
@@ -70,7 +70,7 @@ int g_trace_header[kPyrStages + 1] = {0};
 #ifndef OFX_STREAM_MIN_BLOCKS
 #define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 3)
 #endif
-template <int R, int MODE>
+template <int R, int MODE, bool FAST>
 __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // the short latency-bound stages go first whenever they are ready to issue (the LK waves lower their own priority
         // from 3 to 0 as they advance, lk_body.h)
         __builtin_amdgcn_s_setprio(3);
-        if (b < S.n_corner && wv == 0) corner_wave<MODE>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
+        if (b < S.n_corner && wv == 0) corner_wave<MODE, FAST>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
+        lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -170,24 +170,24 @@ int lk_wave_target(K kernel, int threads, size_t lds, int reserve, int dflt_per_
     return env_int("OFX_LK_TARGET_WAVES", (int)((long)cus * 4 * per_simd * fill / 100));
 }
 
-template <int R, int MODE, bool SUMS>
+template <int R, int MODE, bool SUMS, bool FAST>
 int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS>, 64, 0, 0, 3);
+    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS, FAST>, 64, 0, 0, 3);
     LkTable t{};
     const int blocks = plan_table<R>(lv, n, capacity, &t);
-    hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS>), dim3((unsigned)blocks), dim3(64), 0, st, t);
+    hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS, FAST>), dim3((unsigned)blocks), dim3(64), 0, st, t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
-template <int R, int MODE>
+template <int R, int MODE, bool FAST>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
     // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
-    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 2);
-    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE>, 256, 16 * 1024, 1, 4);
+    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST>, 256, 16 * 1024, 1, 2);
+    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST>, 256, 16 * 1024, 1, 4);
     int pairs = 0;
     for (int i = 0; i < n; ++i) pairs += (lv[i].a.w == lv[0].a.w && lv[i].a.h == lv[0].a.h) ? 1 : 0;
     const int capacity = pairs >= 2 ? capacity2 : capacity1;
@@ -206,54 +206,54 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
         corner_lds = need > corner_lds ? need : corner_lds;
     }
     if (lds < corner_lds) lds = corner_lds;
-    hipLaunchKernelGGL((stream_kernel<R, MODE>), dim3((unsigned)blocks), dim3(256), lds, st, S);
+    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
-template <int MODE>
+template <int MODE, bool FAST>
 int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_stream_r<1, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 2: return launch_stream_r<2, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 3: return launch_stream_r<3, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 4: return launch_stream_r<4, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 5: return launch_stream_r<5, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 6: return launch_stream_r<6, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 7: return launch_stream_r<7, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 8: return launch_stream_r<8, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 9: return launch_stream_r<9, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 10: return launch_stream_r<10, MODE>(lv, n, S, stage_blocks, lds, st);
-    case 11: return launch_stream_r<11, MODE>(lv, n, S, stage_blocks, lds, st);
+    case 1: return launch_stream_r<1, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 2: return launch_stream_r<2, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 3: return launch_stream_r<3, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 4: return launch_stream_r<4, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 5: return launch_stream_r<5, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 6: return launch_stream_r<6, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 7: return launch_stream_r<7, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 8: return launch_stream_r<8, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 9: return launch_stream_r<9, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 10: return launch_stream_r<10, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 11: return launch_stream_r<11, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_stream_r<12, MODE>(lv, n, S, stage_blocks, lds, st);
+        if (radius == 12) return launch_stream_r<12, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
     }
     ofx_set_error("ofx_stream_launch: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
 }
 
-template <int MODE, bool SUMS>
+template <int MODE, bool SUMS, bool FAST>
 int launch_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_r<1, MODE, SUMS>(lv, n, st);
-    case 2: return launch_r<2, MODE, SUMS>(lv, n, st);
-    case 3: return launch_r<3, MODE, SUMS>(lv, n, st);
-    case 4: return launch_r<4, MODE, SUMS>(lv, n, st);
-    case 5: return launch_r<5, MODE, SUMS>(lv, n, st);
-    case 6: return launch_r<6, MODE, SUMS>(lv, n, st);
-    case 7: return launch_r<7, MODE, SUMS>(lv, n, st);
-    case 8: return launch_r<8, MODE, SUMS>(lv, n, st);
-    case 9: return launch_r<9, MODE, SUMS>(lv, n, st);
-    case 10: return launch_r<10, MODE, SUMS>(lv, n, st);
-    case 11: return launch_r<11, MODE, SUMS>(lv, n, st);
+    case 1: return launch_r<1, MODE, SUMS, FAST>(lv, n, st);
+    case 2: return launch_r<2, MODE, SUMS, FAST>(lv, n, st);
+    case 3: return launch_r<3, MODE, SUMS, FAST>(lv, n, st);
+    case 4: return launch_r<4, MODE, SUMS, FAST>(lv, n, st);
+    case 5: return launch_r<5, MODE, SUMS, FAST>(lv, n, st);
+    case 6: return launch_r<6, MODE, SUMS, FAST>(lv, n, st);
+    case 7: return launch_r<7, MODE, SUMS, FAST>(lv, n, st);
+    case 8: return launch_r<8, MODE, SUMS, FAST>(lv, n, st);
+    case 9: return launch_r<9, MODE, SUMS, FAST>(lv, n, st);
+    case 10: return launch_r<10, MODE, SUMS, FAST>(lv, n, st);
+    case 11: return launch_r<11, MODE, SUMS, FAST>(lv, n, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_r<12, MODE, SUMS>(lv, n, st);
+        if (radius == 12) return launch_r<12, MODE, SUMS, FAST>(lv, n, st);
     }
     ofx_set_error("ofx_lk_level: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
@@ -263,7 +263,7 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
 {
     OFX_REQUIRE(d != nullptr && n >= 1 && n <= OFX_MAX_LK_ITEMS, "ofx_lk_levels: bad descriptor count %d", n);
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_lk_level: window must be odd and >= 3 (got %d)", window);
-    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_lk_level: bad mode %d", mode);
+    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT || mode == OFX_MODE_LK_FLOAT_FAST, "ofx_lk_level: bad mode %d", mode);
     const int radius = window >> 1;
     int m = 0;
     for (int i = 0; i < n; ++i) {
@@ -280,6 +280,7 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
         a.next = d[i].d_next;
         a.uv = d[i].d_uv;
         a.accumulate = d[i].accumulate;
+        a.min_det = d[0].min_det; // one value per launch
         a.flow = d[i].d_flow;
         a.sums = d_sums;
         // plane stride of the inspection output = rows from flow_row0 to out_y1
@@ -308,12 +309,13 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
     if (m == 0) return OFX_OK;
     const int radius = window >> 1;
     hipStream_t st = ofx_stream(stream);
-    if (d_sums) {
-        return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, true>(radius, lv, m, st)
-                                         : launch_mode<OFX_MODE_COMPAT_CPU, true>(radius, lv, m, st);
+    if (d_sums) { // the sums do not depend on the solve
+        return mode != OFX_MODE_COMPAT_CPU ? launch_mode<OFX_MODE_LK_FLOAT, true, false>(radius, lv, m, st)
+                                           : launch_mode<OFX_MODE_COMPAT_CPU, true, false>(radius, lv, m, st);
     }
-    return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, false>(radius, lv, m, st)
-                                     : launch_mode<OFX_MODE_COMPAT_CPU, false>(radius, lv, m, st);
+    if (mode == OFX_MODE_LK_FLOAT_FAST) return launch_mode<OFX_MODE_LK_FLOAT, false, true>(radius, lv, m, st);
+    return mode == OFX_MODE_LK_FLOAT ? launch_mode<OFX_MODE_LK_FLOAT, false, false>(radius, lv, m, st)
+                                     : launch_mode<OFX_MODE_COMPAT_CPU, false, false>(radius, lv, m, st);
 }
 
 } // namespace
@@ -322,7 +324,7 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
 {
     OFX_REQUIRE(g != nullptr, "ofx_stream_launch: null argument");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_stream_launch: window must be odd and >= 3 (got %d)", window);
-    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT, "ofx_stream_launch: bad mode %d", mode);
+    OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT || mode == OFX_MODE_LK_FLOAT_FAST, "ofx_stream_launch: bad mode %d", mode);
     OFX_REQUIRE(g->n_pyr >= 0 && g->n_pyr <= OFX_STREAM_MAX_BATCH && g->n_corner >= 0 && g->n_corner <= OFX_STREAM_MAX_BATCH,
                 "ofx_stream_launch: at most %d frames / pairs per tick", OFX_STREAM_MAX_BATCH);
     StreamArgs S{};
@@ -364,8 +366,9 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
-    return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT>(window >> 1, lv, m, S, stage_blocks, lds, st)
-                                     : launch_stream_mode<OFX_MODE_COMPAT_CPU>(window >> 1, lv, m, S, stage_blocks, lds, st);
+    if (mode == OFX_MODE_LK_FLOAT_FAST) return launch_stream_mode<OFX_MODE_LK_FLOAT, true>(window >> 1, lv, m, S, stage_blocks, lds, st);
+    return mode == OFX_MODE_LK_FLOAT ? launch_stream_mode<OFX_MODE_LK_FLOAT, false>(window >> 1, lv, m, S, stage_blocks, lds, st)
+                                     : launch_stream_mode<OFX_MODE_COMPAT_CPU, false>(window >> 1, lv, m, S, stage_blocks, lds, st);
 }
 
 // Debug / measurement hook (tools/stream_timeline.py): with a device buffer of 8 * capacity_blocks uint64 set, every
@@ -389,7 +392,7 @@ extern "C" int ofx_lk_level(const uint8_t *d_prev, const uint8_t *d_next, const 
                             float *d_flow, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_flow && g, "ofx_lk_level: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0, nullptr, 0};
+    ofx_lk_desc d{d_prev, d_next, *g, d_flow, flow_row0, nullptr, 0, 0.0f};
     return lk_dispatch(&d, 1, window, mode, nullptr, stream);
 }
 
@@ -397,6 +400,6 @@ extern "C" int ofx_lk_level_sums(const uint8_t *d_prev, const uint8_t *d_next, c
                                  int32_t *d_sums5, int flow_row0, void *stream)
 {
     OFX_REQUIRE(d_sums5 && g, "ofx_lk_level_sums: null argument");
-    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0, nullptr, 0};
+    ofx_lk_desc d{d_prev, d_next, *g, nullptr, flow_row0, nullptr, 0, 0.0f};
     return lk_dispatch(&d, 1, window, mode, d_sums5, stream);
 }

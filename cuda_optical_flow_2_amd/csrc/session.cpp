@@ -114,14 +114,16 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(p->width > 0 && p->height > 0, "ofx_session_create: bad size %dx%d", p->width, p->height);
     OFX_REQUIRE(p->levels >= 1 && p->levels <= OFX_MAX_LEVELS, "ofx_session_create: levels %d out of range", p->levels);
     OFX_REQUIRE(p->window >= 3 && (p->window & 1), "ofx_session_create: window must be odd and >= 3");
-    OFX_REQUIRE(p->mode == OFX_MODE_COMPAT_CPU || p->mode == OFX_MODE_LK_FLOAT, "ofx_session_create: bad mode %d", p->mode);
+    OFX_REQUIRE(p->mode == OFX_MODE_COMPAT_CPU || p->mode == OFX_MODE_LK_FLOAT || p->mode == OFX_MODE_LK_FLOAT_FAST,
+                "ofx_session_create: bad mode %d", p->mode);
+    OFX_REQUIRE(p->min_det >= 0.0f, "ofx_session_create: min_det must be >= 0 (0 = the reference's unguarded solve)");
     OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
     OFX_REQUIRE(p->stream_batch == 0 || p->stream_batch == 1 || p->stream_batch == 2 || p->stream_batch == 4 ||
                     p->stream_batch == 8,
                 "ofx_session_create: stream_batch %d (0, 1, 2, 4 or 8)", p->stream_batch);
     OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
                 p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
-    OFX_REQUIRE(p->iters <= 1 || (p->mode == OFX_MODE_LK_FLOAT && !p->sharded),
+    OFX_REQUIRE(p->iters <= 1 || (p->mode != OFX_MODE_COMPAT_CPU && !p->sharded),
                 "ofx_session_create: refinement iterations need mode lk_float and an unsharded session");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
                 "ofx_session_create: %d levels is too many for %dx%d", p->levels, p->width, p->height);
@@ -435,7 +437,7 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
     }
     ofx_lk_desc d[OFX_MAX_LEVELS];
     for (int k = 0; k < s->p.levels; ++k)
-        d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr};
+        d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr, 0, s->p.min_det};
     return timed_launch(s, OFX_TIME_CORNER, stream, [&] { return ofx_corner_flows(d, s->p.levels, s->p.window, s->p.mode, s->uv_cur(), stream); });
 }
 
@@ -456,7 +458,7 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
         int nl = 0;
         for (int k = L - 1; k >= 0; --k) // coarse levels first: their few waves start at once and finish early
             lk[nl++] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), s->flow[k], s->own0[k],
-                                   k == L - 1 ? nullptr : uv + 2 * k, 0};
+                                   k == L - 1 ? nullptr : uv + 2 * k, 0, s->p.min_det};
         return timed_lk_launch(s, lk, nl, stream);
     }
     // Extension (DESIGN.md "lk_iter"): iteration 1 is the reference level; every further iteration warps
@@ -470,14 +472,14 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
     auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
     int nl = 0;
     for (int k = L - 1; k >= 0; --k)
-        lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0};
+        lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0, s->p.min_det};
     OFX_TRY(timed_lk_launch(s, lk, nl, stream));
     for (int it = 1; it < s->p.iters; ++it) {
         ofx_warp_desc wd[OFX_MAX_LEVELS];
         nl = 0;
         for (int k = L - 1; k >= 0; --k) {
             wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE};
-            lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1};
+            lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1, s->p.min_det};
             ++nl;
         }
         OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nl, stream); }));
@@ -772,12 +774,12 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
             // (both frames of a pair come through the same API with the same pitch; a borrowed level 0 uses the caller's)
             if (s->p.local_corner) {
                 ofx_geom pg{s->w[k], s->h[k], pitch_of(pc, k, true), 0, s->ph[k], 0, s->ph[k]};
-                C.level[k] = ofx_lk_desc{patch_of(pc - 1, k), patch_of(pc, k), pg, nullptr, 0, nullptr, 0};
+                C.level[k] = ofx_lk_desc{patch_of(pc - 1, k), patch_of(pc, k), pg, nullptr, 0, nullptr, 0, s->p.min_det};
                 C.cols[k] = s->pw[k];
             } else {
                 ofx_geom cg = level_geom(s, k, 0, s->h[k]);
                 cg.pitch = pitch_of(pc, k, false);
-                C.level[k] = ofx_lk_desc{plane_of(pc - 1, k), plane_of(pc, k), cg, nullptr, 0, nullptr, 0};
+                C.level[k] = ofx_lk_desc{plane_of(pc - 1, k), plane_of(pc, k), cg, nullptr, 0, nullptr, 0, s->p.min_det};
             }
         }
         if (s->p.local_corner) {
@@ -792,7 +794,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         for (int k = L - 1; k >= 0; --k) {
             ofx_geom lg = level_geom(s, k, s->own0[k], s->own1[k]);
             lg.pitch = pitch_of(pl, k, false);
-            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0};
+            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0, s->p.min_det};
         }
         newest = pl;
     }

@@ -74,7 +74,8 @@ class Session:
     """Device-resident frame loop (main.cu:192-272): ofx_session_* behind a small object."""
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
-                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False):
+                 shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False,
+                 min_det: float = 0.0):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
@@ -83,6 +84,7 @@ class Session:
         p.local_corner, p.patch_size = int(bool(local_corner)), int(patch_size)
         p.stream_batch = int(stream_batch)
         p.borrow_frames = int(bool(borrow_frames))
+        p.min_det = float(min_det)
         self.shard = shard
         if shard is not None:
             p.sharded = 1
@@ -380,12 +382,12 @@ def warp_u8(src1: np.ndarray, flow: np.ndarray, scale: float) -> np.ndarray:
     return td[:, :w].cpu().numpy()
 
 
-def flow_pair(prev1: np.ndarray, next1: np.ndarray, levels: int, window: int, mode: str, iters: int = 1) -> List[np.ndarray]:
+def flow_pair(prev1: np.ndarray, next1: np.ndarray, levels: int, window: int, mode: str, iters: int = 1, min_det: float = 0.0) -> List[np.ndarray]:
     """Whole pair through a Session: returns the flow pyramid as host arrays."""
     import torch
 
     h, w = prev1.shape
-    s = Session(w, h, levels, window, mode, iters=iters)
+    s = Session(w, h, levels, window, mode, iters=iters, min_det=min_det)
     try:
         s.push_frame_host(prev1)
         s.set_frame_host(next1)

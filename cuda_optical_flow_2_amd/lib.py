@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(PKG, os.environ.get("OFX_LIB", "libofx_hip.so"))  # OFX_
 OFX_MAX_LEVELS = 12
 MODE_COMPAT_CPU = 0
 MODE_LK_FLOAT = 1
-MODES = {"compat_cpu": MODE_COMPAT_CPU, "lk_float": MODE_LK_FLOAT}
+MODE_LK_FLOAT_FAST = 2   # lk_float with the <= 1 ulp solve (include/ofx.h)
+MODES = {"compat_cpu": MODE_COMPAT_CPU, "lk_float": MODE_LK_FLOAT, "lk_float_fast": MODE_LK_FLOAT_FAST}
 SOLVE_F64, SOLVE_INLINE_CPU, SOLVE_F32 = 0, 1, 2
 
 
@@ -36,7 +37,8 @@ class Params(C.Structure):
                 ("own_y0", C.c_int * OFX_MAX_LEVELS), ("own_y1", C.c_int * OFX_MAX_LEVELS),
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
                 ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
-                ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("stream_batch", C.c_int), ("borrow_frames", C.c_int), ("reserved", C.c_int * 3)]
+                ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("stream_batch", C.c_int), ("borrow_frames", C.c_int), ("min_det", C.c_float),
+                ("reserved", C.c_int * 2)]
 
 
 _vp = C.c_void_p

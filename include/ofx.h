@@ -44,6 +44,11 @@ extern "C" {
 #define OFX_MODE_LK_FLOAT 1   /* gpu::calc_opt_flow, OptFlowGpu.cu:1909-1979: float derivatives, Dt_3x3,
                                  double solve */
 
+#define OFX_MODE_LK_FLOAT_FAST 2 /* lk_float with the solve in its <= 1 ulp(float) formulation (SURVEY 8c's tolerance for the
+                                    solve; identical NaN / Inf positions) instead of the replay of the reference's
+                                    operation order: numerators first, reciprocal to 2^-44 -- 11 double operations per
+                                    pixel instead of 19.  Everything else (window sums, shift, pyramid) is bit-exact. */
+
 #define OFX_MAX_LEVELS 12
 #define OFX_MAX_LK_ITEMS 40 /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
 
@@ -96,6 +101,11 @@ typedef struct ofx_lk_desc {
      * OptFlowCPU.cpp:241-282, fused into the row loads) -- same bits as shifting first, without the extra pass. */
     const float *d_uv;
     int accumulate; /* non-zero: d_flow += result (refinement iterations, ofx_warp_levels) instead of d_flow = result */
+    /* Extension (the reference divides unguarded, OptFlowGpu.cu:1833-1838 / OptFlowCPU.cpp:369-372, and writes
+     * NaN / Inf / huge vectors where a window has no texture or a single edge): > 0 = a pixel whose determinant Sxx*Syy - Sxy^2,
+     * rounded to float, is below min_det gets the flow (0, 0).  0 = the reference.  One value per launch: the first
+     * descriptor's. */
+    float min_det;
 } ofx_lk_desc;
 int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
 
@@ -322,7 +332,9 @@ typedef struct ofx_params {
      * Saves 2 bytes per level-0 pixel of HBM traffic per frame (at 4K: 13 % of a four-frame tick, most of it the
      * write-back of the copy's dirty lines between launches).  0 = copy (any buffer lifetime). */
     int borrow_frames;
-    int reserved[3];
+    /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */
+    float min_det;
+    int reserved[2];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
