@@ -44,6 +44,7 @@ struct __attribute__((packed)) UnalignedU32 {
     uint32_t v;
 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (base: wave-uniform pointer; off: per-lane unsigned byte / element offset -- the cast is applied to the base so that
 // the access selects as "SGPR base + 32-bit VGPR offset"; the offset is made opaque at the access because instruction
 // selection only forms that addressing mode when the 32->64-bit extension sits in the same block as the access, and
@@ -96,6 +97,15 @@ __device__ __forceinline__ void gstore_f32x2(gfloat_ptr p, float a, float b)
     __builtin_nontemporal_store(f32x2{a, b}, (OFX_GLOBAL f32x2 *)p);
 #else
     *(OFX_GLOBAL f32x2 *)p = f32x2{a, b};
+#endif
+}
+__device__ __forceinline__ void gstore_f32x4(gfloat_ptr p, f32x4 v)
+{
+    typedef float f32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+#if OFX_LK_NT_STORES
+    __builtin_nontemporal_store((f32x4_a8)v, (OFX_GLOBAL f32x4_a8 *)p);
+#else
+    *(OFX_GLOBAL f32x4_a8 *)p = (f32x4_a8)v;
 #endif
 }
 __device__ __forceinline__ void gstore_i32(int32_t *p, int32_t v) { *(OFX_GLOBAL int32_t *)p = v; }
@@ -550,12 +560,27 @@ __device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&i
     }
 }
 
+// ---- the flow stores ------------------------------------------------------------------------------------------------------
+// A lane ends a step with the (u,v) pairs of its 4 pixels: 32 contiguous bytes, 2 KB per wave and row.  Written as they
+// lie -- two dwordx4 per lane -- each store instruction covers every other 16 bytes of that range, and streaming
+// (non-temporal) stores, which the kernel needs so that the flow does not evict the image rows from L2, are then written
+// to memory as half-filled sectors: tools/ubench/store_patterns.hip measures 2.5 TB/s for that shape against 5.3-5.6 TB/s
+// when every instruction covers whole 128-byte lines (runs of >= 8 lanes x 16 B), and 354 MB of flow per four 4K pairs at
+// 2.6 TB/s is the 135 us the launch took however little arithmetic was left in it (profiles/r02_*).  So the wave first
+// exchanges the row through LDS -- each lane writes its 32 bytes, then reads the two 16-byte chunks l and l + 64 of the
+// row (counted from the first valid byte) -- and both store instructions cover 1 KB without gaps, starting on the tile's
+// first output byte, which is 128-byte aligned whenever the level's row pitch is (every BASELINE level).  LDS instructions
+// issue beside the VALU, a wave's LDS operations execute in order, and the region is private to the wave: no barrier.
+constexpr int kLkWaveLds = 2048 + 128; // one row of a wave + the reads of the lanes past its valid end
+typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
+
 // One wave of the fused level kernel: `wave` indexes the (level, tile, strip) work items of the table, `lane` is 0..63.
 // MAY_ACC: the launch may contain accumulating items (refinement iterations); false compiles that path out (the stream
 // kernel never has any, and the extra live registers would push it over its 96-VGPR budget)
 // FAST: the <= 1 ulp solve (lk_solve.h) instead of the replay of the reference's operation order
+// xlds: kLkWaveLds bytes of LDS private to this wave (the exchange in front of the flow stores, below)
 template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false>
-__device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
+__device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
@@ -606,6 +631,16 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
     }
     uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
     uint32_t flow_off = 8u * (uint32_t)(cb > 0 ? cb : 0); // byte offset of this lane's first (u,v) pair in a flow row
+    // the exchanged layout: chunk c of the row (16 bytes = pixels x0 + 2c, x0 + 2c + 1, x0 = the tile's first output column)
+    // is written by lane c (first store) or c - 64 (second store); px_lo / px_hi = the first pixel of this lane's two chunks
+    const int x0 = tile * G::OUT_W;
+    const int px_lo = x0 + 2 * lane, px_hi = px_lo + 128;
+    const int x_end = min(x0 + G::OUT_W, A.w);           // one past the tile's last output column
+    uint32_t xoff_lo = 8u * (uint32_t)px_lo, xoff_hi = 8u * (uint32_t)px_hi;
+    const int n_lo = min(max(x_end - px_lo, 0), 2), n_hi = min(max(x_end - px_hi, 0), 2); // valid pixels of each chunk
+    // LDS: lane l's 32 bytes go to offset 32 l; the tile's first output byte is lane LO_LANE's, so chunk c sits at 32 LO + 16 c
+    const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
+    const lds_ptr xl_r = (lds_ptr)xlds + 32 * G::LO_LANE + 16 * lane;
 
     // rows outside the image are the zero border; rows past the last one this strip needs (the loop prefetches one
     // row ahead) or outside the buffer are never dereferenced.  The row test is wave-uniform (scalar branch); lanes
@@ -854,58 +889,74 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane)
 #endif
         int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
         float uv[8];
+        f32x4 xlo = {0.0f, 0.0f, 0.0f, 0.0f}, xhi = {0.0f, 0.0f, 0.0f, 0.0f}; // this lane's two chunks of the exchanged row
         if (emit) {
+#ifdef OFX_X_NOHBOX // timing experiments (OFX_BUILD_DEFS): what a stage costs is what the launch gains without it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hxx[j] = vxx[j], hyy[j] = vyy[j], hxy[j] = vxy[j], hxt[j] = vxt[j], hyt[j] = vyt[j];
+#else
             hbox4<R>(vxx, hxx);
             hbox4<R>(vyy, hyy);
             hbox4<R>(vxy, hxy);
             hbox4<R>(vxt, hxt);
             hbox4<R>(vyt, hyt);
+#endif
             if constexpr (!SUMS) {
                 // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
 #pragma unroll
-                for (int j = 0; j < 4; ++j) solve2x2<MODE, FAST>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], sopt, uv[2 * j], uv[2 * j + 1]);
+                for (int j = 0; j < 4; ++j) {
+#ifdef OFX_X_NOSOLVE
+                    uv[2 * j] = __int_as_float(hxx[j] ^ hxy[j] ^ hxt[j]);
+                    uv[2 * j + 1] = __int_as_float(hyy[j] ^ hyt[j]);
+#else
+                    solve2x2<MODE, FAST>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], sopt, uv[2 * j], uv[2 * j + 1]);
+#endif
+                }
+                if constexpr (MAY_ACC) {
+                    if (A.accumulate) { // (old_uv is zero in the lanes that do not store)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) uv[j] = old_uv[j] + uv[j];
+                    }
+                }
+                // exchange the row through LDS (see "the flow stores" above): in as it lies, out as two gap-free runs
+                *(__attribute__((address_space(3))) f32x4 *)(xl_w) = f32x4{uv[0], uv[1], uv[2], uv[3]};
+                *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                xlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
+                xhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
             }
         }
         take_rows();
-        if (emit && out_lane) {
+        if (emit) {
             if constexpr (SUMS) {
-                const size_t pix = rowpix + (uint32_t)cb;
+                if (out_lane) {
+                    const size_t pix = rowpix + (uint32_t)cb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (cb + j < A.w) {
-                        gstore_i32(A.sums + pix + j, hxx[j]);
-                        gstore_i32(A.sums + A.sums_plane + pix + j, hyy[j]);
-                        gstore_i32(A.sums + 2 * A.sums_plane + pix + j, hxy[j]);
-                        gstore_i32(A.sums + 3 * A.sums_plane + pix + j, hxt[j]);
-                        gstore_i32(A.sums + 4 * A.sums_plane + pix + j, hyt[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        if (cb + j < A.w) {
+                            gstore_i32(A.sums + pix + j, hxx[j]);
+                            gstore_i32(A.sums + A.sums_plane + pix + j, hyy[j]);
+                            gstore_i32(A.sums + 2 * A.sums_plane + pix + j, hxy[j]);
+                            gstore_i32(A.sums + 3 * A.sums_plane + pix + j, hxt[j]);
+                            gstore_i32(A.sums + 4 * A.sums_plane + pix + j, hyt[j]);
+                        }
                     }
                 }
             } else {
                 float *frow = A.flow + 2 * rowpix;
                 pin_scalar(frow);
-                if constexpr (MAY_ACC) {
-                    if (A.accumulate) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) uv[j] = old_uv[j] + uv[j];
-                    }
-                }
                 // (the address is formed inside each branch: instruction selection only picks the scalar-base form when the
-                // offset's extension sits in the block of the access)
-                if (cb + 3 < A.w) {
-                    // 32 contiguous bytes per lane; the address is only 8-byte aligned in general (odd w*y)
-                    const gfloat_ptr dst = gptr_f32_var(frow, flow_off);
-                    gstore_f32x2(dst, uv[0], uv[1]);
-                    gstore_f32x2(dst + 2, uv[2], uv[3]);
-                    gstore_f32x2(dst + 4, uv[4], uv[5]);
-                    gstore_f32x2(dst + 6, uv[6], uv[7]);
-                } else {
-                    const gfloat_ptr dst = gptr_f32_var(frow, flow_off);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (cb + j < A.w) {
-                            dst[2 * j] = uv[2 * j];
-                            dst[2 * j + 1] = uv[2 * j + 1];
-                        }
+                // offset's extension sits in the block of the access; it is only 8-byte aligned in general -- odd w*y)
+                if (n_lo == 2) {
+                    gstore_f32x4(gptr_f32_var(frow, xoff_lo), xlo);
+                } else if (n_lo == 1) { // a level of odd width ends inside this chunk
+                    gstore_f32x2(gptr_f32_var(frow, xoff_lo), xlo.x, xlo.y);
+                }
+                if (n_hi == 2) {
+                    gstore_f32x4(gptr_f32_var(frow, xoff_hi), xhi);
+                } else if (n_hi == 1) {
+                    gstore_f32x2(gptr_f32_var(frow, xoff_hi), xhi.x, xhi.y);
                 }
             }
         }

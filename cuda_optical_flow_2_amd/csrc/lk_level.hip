@@ -37,7 +37,8 @@ namespace {
 template <int R, int MODE, bool SUMS, bool FAST>
 __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const LkTable T)
 {
-    lk_wave<R, MODE, SUMS, true, FAST>(T, (int)blockIdx.x, (int)threadIdx.x);
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[kLkWaveLds];
+    lk_wave<R, MODE, SUMS, true, FAST>(T, (int)blockIdx.x, (int)threadIdx.x, xlds);
 }
 
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         __builtin_amdgcn_s_setprio(3);
         if (b < S.n_corner && wv == 0) corner_wave<MODE, FAST>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63);
+        lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLds);
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -206,6 +207,7 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
         corner_lds = need > corner_lds ? need : corner_lds;
     }
     if (lds < corner_lds) lds = corner_lds;
+    if (lds < 4 * (size_t)kLkWaveLds) lds = 4 * (size_t)kLkWaveLds; // an LK block: four waves, each with its exchange row
     hipLaunchKernelGGL((stream_kernel<R, MODE, FAST>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;

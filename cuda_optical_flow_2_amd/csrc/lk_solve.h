@@ -109,7 +109,10 @@ __device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int
     } else {
         solve_tail_exact<MODE>(a, b, d, xt, yt, det, u, v);
     }
-    if (opt.min_det > 0.0f) { // wave-uniform: the guard costs nothing when it is off
+    if (__builtin_expect(opt.min_det > 0.0f, 0)) { // wave-uniform
+        // the empty asm keeps this block a real branch: if-converted (as hipcc does with a plain block), the guard's
+        // conversion, compare and two selects ran for every pixel of every launch -- 5 % of the level kernel -- while off
+        asm volatile("" : "+v"(u), "+v"(v));
         if (!((float)det >= opt.min_det)) {
             u = 0.0f;
             v = 0.0f;

@@ -1,0 +1,29 @@
+# SQ counters of one kernel for one configuration, separate rocprofv3 --pmc passes (no tracing alongside):
+#   bash tools/pmc_counters.sh <out dir under gpurun_out> <kernel substring> <pmc_run.py args...>
+# prints, per counter, the mean over the launches of that kernel (first 3 skipped)
+set -e
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$1; K=$2; shift 2
+rm -rf $O; mkdir -p $O
+cd $R
+for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+  T=$(echo $C | tr ' ' '_')
+  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python tools/pmc_run.py "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
+done
+python - "$O" "$K" <<'PY'
+import csv, glob, os, sys
+root, k = sys.argv[1], sys.argv[2]
+for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
+    per = {}
+    for row in csv.DictReader(open(f)):
+        if k not in row.get("Kernel_Name", ""): continue
+        key = (row["Counter_Name"], int(row["Dispatch_Id"]))
+        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+    by = {}
+    for (c, d), v in sorted(per.items(), key=lambda kv: kv[0][1]): by.setdefault(c, []).append(v)
+    for c, l in by.items():
+        l = l[3:] if len(l) > 3 else l
+        print(f"{c:24s} {sum(l)/len(l):14.4g}   ({len(l)} launches)")
+PY
+find $O -name "*counter_collection.csv" -size +1M -delete

@@ -1,5 +1,5 @@
 """Tiny workload for rocprofv3 --pmc passes at a BASELINE size.
-    python tools/pmc_run.py [4k|1080p|8k] [plain|stream]
+    python tools/pmc_run.py [4k|1080p|8k] [plain|stream] [lk_float|lk_float_fast|compat_cpu] [iters]
 plain: a few all-level lk_level_kernel launches of one pair; stream: a few stream_kernel launches (one per frame)."""
 import sys
 import torch
@@ -7,10 +7,12 @@ sys.path.insert(0, ".")
 from cuda_optical_flow_2_amd import engine, synth
 cfg = {"4k": (3840, 2160, 5, 9), "1080p": (1920, 1080, 4, 7), "8k": (7680, 4320, 6, 15)}[sys.argv[1] if len(sys.argv) > 1 else "4k"]
 path = sys.argv[2] if len(sys.argv) > 2 else "plain"
+mode = sys.argv[3] if len(sys.argv) > 3 else "lk_float"
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 w, h, L, win = cfg
 p, n = synth.smooth_pair(w, h)
 B = engine.suggest_stream_batch(w, h, L, None, True)  # as bench.py runs it: borrowed frames from a ring of distinct buffers
-s = engine.Session(w, h, L, win, "lk_float", stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream")
+s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters)
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     if path == "plain":
