@@ -632,15 +632,14 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
     uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
     uint32_t flow_off = 8u * (uint32_t)(cb > 0 ? cb : 0); // byte offset of this lane's first (u,v) pair in a flow row
     // the exchanged layout: chunk c of the row (16 bytes = pixels x0 + 2c, x0 + 2c + 1, x0 = the tile's first output column)
-    // is written by lane c (first store) or c - 64 (second store); px_lo / px_hi = the first pixel of this lane's two chunks
+    // is written by lane c (first store) or c - 64 (second store).  Everything per lane derives from 16 * lane, so that the
+    // exchange costs two VGPRs: chunk c holds min(max(nv - 2c, 0), 2) valid pixels, nv = the tile's output columns.
     const int x0 = tile * G::OUT_W;
-    const int px_lo = x0 + 2 * lane, px_hi = px_lo + 128;
-    const int x_end = min(x0 + G::OUT_W, A.w);           // one past the tile's last output column
-    uint32_t xoff_lo = 8u * (uint32_t)px_lo, xoff_hi = 8u * (uint32_t)px_hi;
-    const int n_lo = min(max(x_end - px_lo, 0), 2), n_hi = min(max(x_end - px_hi, 0), 2); // valid pixels of each chunk
+    const int nv = min(x0 + G::OUT_W, A.w) - x0;
+    uint32_t l16 = 16u * (uint32_t)lane;
     // LDS: lane l's 32 bytes go to offset 32 l; the tile's first output byte is lane LO_LANE's, so chunk c sits at 32 LO + 16 c
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
-    const lds_ptr xl_r = (lds_ptr)xlds + 32 * G::LO_LANE + 16 * lane;
+    const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
 
     // rows outside the image are the zero border; rows past the last one this strip needs (the loop prefetches one
     // row ahead) or outside the buffer are never dereferenced.  The row test is wave-uniform (scalar branch); lanes
@@ -903,15 +902,15 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
 #endif
             if constexpr (!SUMS) {
                 // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
+#ifdef OFX_X_NOSOLVE
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-#ifdef OFX_X_NOSOLVE
                     uv[2 * j] = __int_as_float(hxx[j] ^ hxy[j] ^ hxt[j]);
                     uv[2 * j + 1] = __int_as_float(hyy[j] ^ hyt[j]);
-#else
-                    solve2x2<MODE, FAST>(hxx[j], hyy[j], hxy[j], hxt[j], hyt[j], sopt, uv[2 * j], uv[2 * j + 1]);
-#endif
                 }
+#else
+                solve_lane<MODE, FAST>(hxx, hyy, hxy, hxt, hyt, sopt, uv);
+#endif
                 if constexpr (MAY_ACC) {
                     if (A.accumulate) { // (old_uv is zero in the lanes that do not store)
 #pragma unroll
@@ -923,6 +922,7 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
                 *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                const lds_ptr xl_r = xl_base + lane_off_var(l16);
                 xlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
                 xhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
             }
@@ -944,19 +944,22 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
                     }
                 }
             } else {
-                float *frow = A.flow + 2 * rowpix;
+                float *frow = A.flow + 2 * (rowpix + (size_t)x0); // the tile's first output pixel of this row
                 pin_scalar(frow);
-                // (the address is formed inside each branch: instruction selection only picks the scalar-base form when the
-                // offset's extension sits in the block of the access; it is only 8-byte aligned in general -- odd w*y)
-                if (n_lo == 2) {
-                    gstore_f32x4(gptr_f32_var(frow, xoff_lo), xlo);
-                } else if (n_lo == 1) { // a level of odd width ends inside this chunk
-                    gstore_f32x2(gptr_f32_var(frow, xoff_lo), xlo.x, xlo.y);
+                // chunk c: both pixels valid <=> 16 c <= 8 nv - 16; only the first (a level of odd width ends inside it) <=>
+                // 16 c == 8 nv - 8.  (The address is formed inside each branch: instruction selection only picks the
+                // scalar-base form when the offset's extension sits in the block of the access; it is only 8-byte aligned
+                // in general -- odd w*y.)
+                const int lim = 8 * nv - 16;
+                if ((int)l16 <= lim) {
+                    gstore_f32x4(gptr_f32_var(frow, l16), xlo);
+                } else if ((int)l16 == lim + 8) {
+                    gstore_f32x2(gptr_f32_var(frow, l16), xlo.x, xlo.y);
                 }
-                if (n_hi == 2) {
-                    gstore_f32x4(gptr_f32_var(frow, xoff_hi), xhi);
-                } else if (n_hi == 1) {
-                    gstore_f32x2(gptr_f32_var(frow, xoff_hi), xhi.x, xhi.y);
+                if ((int)l16 <= lim - 1024) {
+                    gstore_f32x4(gptr_f32_var(frow, l16) + 256, xhi);
+                } else if ((int)l16 == lim - 1016) {
+                    gstore_f32x2(gptr_f32_var(frow, l16) + 256, xhi.x, xhi.y);
                 }
             }
         }

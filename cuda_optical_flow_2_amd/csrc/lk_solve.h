@@ -57,65 +57,123 @@ __device__ __forceinline__ void solve_tail_exact(double a, double b, double d, d
 
 // FAST: lk_float only.  The reference computes u = -(d/det)*xt + (b/det)*yt in double and rounds to float.  Here the
 // numerators come first: with 24-bit operands d*xt and b*yt are exact in double, so nu = fma(b, yt, -(d*xt)) is the exact
-// numerator rounded ONCE, and u = float(nu * p) with p = 1/det good to 2^-44 (seed + one Newton step) -- 11 double
-// operations per pixel instead of 19.  Against the replay this is within 1 float ulp (measured: identical bits for
-// 99.999 % of the pixels of every test image, 1 ulp for the rest; the bound fails only where the reference's own rounding
-// noise, 3 * 2^-53 * (|d' xt| + |b' yt|), exceeds a float ulp of the result, i.e. a numerator that cancels to less than
-// 2^-27 of its terms).  A pixel with det == 0 takes the replay's path, so NaN / Inf appear exactly where the reference
-// produces them; the choice is per pixel (a lane's result never depends on its neighbours in the wave), which keeps
-// sharded and tiled runs bit-identical to whole-frame ones.
-template <int MODE, bool FAST>
-__device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int syt, const SolveOpts &opt, float &u, float &v)
+// numerator rounded ONCE, and u = float(nu * p) with p = 1/det good to 2^-44 (seed + one Newton step) -- 24 instructions
+// per pixel instead of 30.  Against the replay this is within 1 float ulp (measured: identical bits for 99.999 % of the
+// pixels of every test image, 1 ulp for the rest; the bound fails only where the reference's own rounding noise,
+// 3 * 2^-53 * (|d' xt| + |b' yt|), exceeds a float ulp of the result, i.e. a numerator that cancels to less than 2^-27 of
+// its terms).  A pixel with det == 0 takes the replay's path, so NaN / Inf appear exactly where the reference produces
+// them; the choice is per pixel (a lane's result never depends on its neighbours in the wave), which keeps sharded and
+// tiled runs bit-identical to whole-frame ones.  The test for it costs one compare per pixel: solve_fast reports the lanes
+// with det == 0 as a wave mask (scalar registers) and the caller branches on it.
+template <int MODE>
+__device__ __forceinline__ void solve_operands(int sxx, int syy, int sxy, int sxt, int syt, double &a, double &b, double &d, double &xt,
+                                               double &yt, double &det)
 {
-    static_assert(!FAST || MODE == OFX_MODE_LK_FLOAT, "the fast solve is defined for lk_float only");
-    double a, b, d, xt, yt;
     if constexpr (MODE == OFX_MODE_LK_FLOAT) {
         a = (double)(float)sxx;
         b = (double)(float)sxy;
         d = (double)(float)syy;
         xt = (double)(float)sxt;
         yt = (double)(float)syt;
+        // a, b, d carry 24 significant bits, so a*d and b*c are exact in double and (a*d) - (b*c) rounds once: the fused
+        // form rounds the same exact difference once -- identical bits, one instruction less
+        det = __builtin_fma(a, d, -(b * b));
     } else {
         a = (double)sxx;
         b = (double)sxy;
         d = (double)syy;
         xt = (double)sxt;
         yt = (double)syt;
-    }
-    double det;
-    if constexpr (MODE == OFX_MODE_LK_FLOAT) {
-        // a, b, d carry 24 significant bits, so a*d and b*c are exact in double and (a*d) - (b*c) rounds once: the fused
-        // form rounds the same exact difference once -- identical bits, one instruction less
-        det = __builtin_fma(a, d, -(b * b));
-    } else {
         det = a * d - b * b; // 31-bit factors: the products themselves round, keep the reference's three operations
     }
+}
+
+// returns the wave mask of the lanes whose determinant is zero (their u, v are not the reference's yet: solve_fix_singular)
+__device__ __forceinline__ unsigned long long solve_fast(int sxx, int syy, int sxy, int sxt, int syt, float &u, float &v)
+{
+    double a, b, d, xt, yt, det;
+    solve_operands<OFX_MODE_LK_FLOAT>(sxx, syy, sxy, sxt, syt, a, b, d, xt, yt, det);
+    const double nu = __builtin_fma(b, yt, -(d * xt));
+    const double nv = __builtin_fma(b, xt, -(a * yt));
+    double p = __builtin_amdgcn_rcp(det);
+    const double e = __builtin_fma(-det, p, 1.0);
+    p = __builtin_fma(p, e, p);
+    u = (float)(nu * p);
+    v = (float)(nv * p);
+    return __ballot(det == 0.0);
+}
+
+// the rare path behind solve_fast: the lanes of `zero` take the replay's result
+__device__ __forceinline__ void solve_fix_singular(int sxx, int syy, int sxy, int sxt, int syt, float &u, float &v)
+{
+    double a, b, d, xt, yt, det;
+    solve_operands<OFX_MODE_LK_FLOAT>(sxx, syy, sxy, sxt, syt, a, b, d, xt, yt, det);
+    float eu, ev;
+    solve_tail_exact<OFX_MODE_LK_FLOAT>(a, b, d, xt, yt, det, eu, ev);
+    if (det == 0.0) {
+        u = eu;
+        v = ev;
+    }
+}
+
+// the determinant guard (SolveOpts::min_det), applied after the solve where it is on
+template <int MODE>
+__device__ __forceinline__ void solve_guard(int sxx, int syy, int sxy, float min_det, float &u, float &v)
+{
+    double a, b, d, xt, yt, det;
+    solve_operands<MODE>(sxx, syy, sxy, 0, 0, a, b, d, xt, yt, det);
+    if (!((float)det >= min_det)) {
+        u = 0.0f;
+        v = 0.0f;
+    }
+}
+
+// One pixel, complete (corner kernel).
+template <int MODE, bool FAST>
+__device__ __forceinline__ void solve2x2(int sxx, int syy, int sxy, int sxt, int syt, const SolveOpts &opt, float &u, float &v)
+{
+    static_assert(!FAST || MODE == OFX_MODE_LK_FLOAT, "the fast solve is defined for lk_float only");
     if constexpr (FAST) {
-        const double nu = __builtin_fma(b, yt, -(d * xt));
-        const double nv = __builtin_fma(b, xt, -(a * yt));
-        double p = __builtin_amdgcn_rcp(det);
-        const double e = __builtin_fma(-det, p, 1.0);
-        p = __builtin_fma(p, e, p);
-        u = (float)(nu * p);
-        v = (float)(nv * p);
-        if (__any(det == 0.0)) { // wave-uniform branch, rare: the pixels concerned take the reference's path
-            float eu, ev;
-            solve_tail_exact<MODE>(a, b, d, xt, yt, det, eu, ev);
-            if (det == 0.0) {
-                u = eu;
-                v = ev;
-            }
-        }
+        if (solve_fast(sxx, syy, sxy, sxt, syt, u, v) != 0ull) solve_fix_singular(sxx, syy, sxy, sxt, syt, u, v);
     } else {
+        double a, b, d, xt, yt, det;
+        solve_operands<MODE>(sxx, syy, sxy, sxt, syt, a, b, d, xt, yt, det);
         solve_tail_exact<MODE>(a, b, d, xt, yt, det, u, v);
     }
     if (__builtin_expect(opt.min_det > 0.0f, 0)) { // wave-uniform
         // the empty asm keeps this block a real branch: if-converted (as hipcc does with a plain block), the guard's
         // conversion, compare and two selects ran for every pixel of every launch -- 5 % of the level kernel -- while off
         asm volatile("" : "+v"(u), "+v"(v));
-        if (!((float)det >= opt.min_det)) {
-            u = 0.0f;
-            v = 0.0f;
+        solve_guard<MODE>(sxx, syy, sxy, opt.min_det, u, v);
+    }
+}
+
+// The 4 pixels of a lane of the level kernel.
+template <int MODE, bool FAST>
+__device__ __forceinline__ void solve_lane(const int (&sxx)[4], const int (&syy)[4], const int (&sxy)[4], const int (&sxt)[4],
+                                           const int (&syt)[4], const SolveOpts &opt, float (&uv)[8])
+{
+    if constexpr (FAST) {
+        // (pixel by pixel: a pixel's five sums die with its solve -- one branch per row step for all four pixels kept all
+        // twenty sums alive for the singular path and spilled)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (__builtin_expect(solve_fast(sxx[j], syy[j], sxy[j], sxt[j], syt[j], uv[2 * j], uv[2 * j + 1]) != 0ull, 0)) {
+                asm volatile("" : "+v"(uv[2 * j]), "+v"(uv[2 * j + 1]));
+                solve_fix_singular(sxx[j], syy[j], sxy[j], sxt[j], syt[j], uv[2 * j], uv[2 * j + 1]);
+            }
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double a, b, d, xt, yt, det;
+            solve_operands<MODE>(sxx[j], syy[j], sxy[j], sxt[j], syt[j], a, b, d, xt, yt, det);
+            solve_tail_exact<MODE>(a, b, d, xt, yt, det, uv[2 * j], uv[2 * j + 1]);
+        }
+    }
+    if (__builtin_expect(opt.min_det > 0.0f, 0)) {
+        asm volatile("" : "+v"(uv[0]), "+v"(uv[1]), "+v"(uv[2]), "+v"(uv[3]), "+v"(uv[4]), "+v"(uv[5]), "+v"(uv[6]), "+v"(uv[7]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) solve_guard<MODE>(sxx[j], syy[j], sxy[j], opt.min_det, uv[2 * j], uv[2 * j + 1]);
     }
 }

@@ -903,3 +903,151 @@ def test_full_size_properties(eng, cfg):
     med = np.nanmedian(a[0].reshape(-1, 2), axis=0)
     assert np.isfinite(med).all()
     s.close()
+
+
+# ---- solve options: OFX_MODE_LK_FLOAT_FAST (<= 1 ulp) and the determinant guard ------------------------------------------
+
+def _stripes(w, h, ang, shift):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    t = np.cos(ang) * xx + np.sin(ang) * yy
+    return np.clip(127 + 100 * np.sin((t - shift) * 0.3), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("case", ["smooth", "random", "stripes45", "stripes_x", "stripes17", "flat", "identical"])
+def test_fast_solve_is_within_one_ulp_of_the_replay(eng, case):
+    """OFX_MODE_LK_FLOAT_FAST: numerators first, reciprocal to 2^-44 (csrc/lk_solve.h).  SURVEY 8c's tolerance for the solve:
+    identical NaN / Inf positions, finite values within 1 float ulp of the replayed reference solve -- on textures,
+    noise, and on the degenerate inputs where the 2x2 system is singular (exactly: axis-parallel and 45-degree stripes,
+    flat frames; nearly: 17-degree stripes), where every pixel with det == 0 must take the replay's path."""
+    w, h, win = 1000, 600, 9
+    if case == "smooth":
+        p, n = synth.smooth_pair(w, h, 2.0, 1.0)
+    elif case == "random":
+        p, n = synth.random_pair(w, h)
+    elif case == "flat":
+        p = np.full((h, w), 77, np.uint8); n = np.full((h, w), 80, np.uint8)
+    elif case == "identical":
+        p, _ = synth.smooth_pair(w, h); n = p.copy()
+    else:
+        ang = {"stripes45": np.pi / 4, "stripes_x": 0.0, "stripes17": 0.3}[case]
+        p, n = _stripes(w, h, ang, 0.0), _stripes(w, h, ang, 0.7)
+    exact = eng.lk_level(p, n, win, "lk_float")
+    fast = eng.lk_level(p, n, win, "lk_float_fast")
+    assert_flow_close(fast, exact, 1, f"fast solve, {case}")
+    if case in ("smooth", "random"):
+        same = (fast == exact) | (np.isnan(fast) & np.isnan(exact))
+        assert same.mean() > 0.9999, same.mean()   # the two formulations agree to the bit almost everywhere
+
+
+def test_fast_solve_through_every_path(eng):
+    """lk_float_fast through the session: plain sequence, stream pipeline (two frames per launch) and 3 row shards give the
+    same bits as each other (the choice of formula is per pixel, never per wave), and stay within 1 ulp of lk_float."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, nf = 640, 480, 3, 9, 6
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=11)[1]).cuda() for i in range(nf)]
+
+    def plain(mode):
+        s = eng.Session(w, h, L, win, mode)
+        s.set_frame_device(frames[0]); s.build_pyramid(); s.swap()
+        out = {}
+        for i in range(1, nf):
+            s.set_frame_device(frames[i]); s.build_pyramid(); s.run_flow()
+            torch.cuda.synchronize()
+            out[i] = [s.flow_host(k) for k in range(L)]
+            s.swap()
+        s.close()
+        return out
+
+    exact, fast = plain("lk_float"), plain("lk_float_fast")
+    for i in exact:
+        for k in range(L):
+            assert_flow_close(fast[i][k], exact[i][k], 1, f"pair {i} level {k}")
+    for R in (1, 3):
+        ranks = [eng.Session(w, h, L, win, "lk_float_fast", stream_batch=2, shard=None if R == 1 else ShardPlan(w, h, L, win, r, R),
+                             local_corner=R > 1) for r in range(R)]
+        got, seen = {}, 0
+        for s in ranks:
+            s.stream_begin()
+
+        def snap(done):
+            nonlocal seen
+            if done >= 1:
+                for p in range(max(seen + 1, done - 1), done + 1):
+                    got[p] = [torch.cat([s.flow_of(p, k)[0] for s in ranks], dim=0).cpu().numpy() for k in range(L)]
+                seen = done
+        for f in frames:
+            snap([s.stream_submit(f) for s in ranks][0])
+        while True:
+            d = [s.stream_drain() for s in ranks][0]
+            if d == -2:
+                break
+            snap(d)
+        for i in range(1, nf):
+            for k in range(L):
+                assert_same(got[i][k], fast[i][k], f"{R} rank(s), stream: pair {i} level {k}")
+        for s in ranks:
+            s.close()
+
+
+def test_determinant_guard(eng, oracle):
+    """ofx_params.min_det (extension): pixels whose determinant, rounded to float, is below the threshold get the
+    flow (0, 0) instead of the reference's unguarded quotient; everything else keeps the reference's bits; min_det = 0 is
+    the reference.  Checked on a single level against the oracle's sums (the guard is a function of Sxx, Syy, Sxy only), in
+    both modes, and through a whole session (where the guarded pixel 0 also feeds the shift vectors) for consistency
+    between the plain and the stream path."""
+    import torch
+
+    w, h, win = 640, 360, 9
+    p, n = synth.smooth_pair(w, h, 1.0, 0.5)
+    p[100:200, 200:400] = 90; n[100:200, 200:400] = 93          # a flat patch: det == 0 inside it
+    for mode in ("lk_float", "compat_cpu"):
+        ref = eng.lk_level(p, n, win, mode)
+        sums = eng.lk_level(p, n, win, mode, want_sums=True).astype(np.float64)
+        if mode == "lk_float":
+            a, d, b = (sums[i].astype(np.float32).astype(np.float64) for i in (0, 1, 2))
+        else:
+            a, d, b = sums[0], sums[1], sums[2]
+        det = (a * d - b * b).astype(np.float32)
+        thr = float(np.percentile(det, 30))
+        s = eng.Session(w, h, 1, win, mode, min_det=thr)
+        s.push_frame_host(p); s.set_frame_host(n); s.build_pyramid(); s.run_flow()
+        torch.cuda.synchronize()
+        got = s.flow_host(0)
+        s.close()
+        low = ~(det >= np.float32(thr))
+        assert low.sum() > 1000 and (~low).sum() > 1000
+        assert (got[low] == 0).all(), "guarded pixels must be exactly (0, 0)"
+        assert_same(got[~low], ref[~low], f"{mode}: pixels above the threshold keep the reference's bits")
+        assert np.isnan(ref[150, 300]).all() and (got[150, 300] == 0).all()   # the flat patch: NaN in the reference
+    # whole sessions: plain == stream with the guard on, 3 levels
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, 0.4 * i, seed=3)[1]).cuda() for i in range(5)]
+    plain = eng.Session(w, h, 3, win, "lk_float", min_det=5e9)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, 5):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(3)]
+        plain.swap()
+    plain.close()
+    assert any((want[i][0] == 0).all(axis=2).mean() > 0.01 for i in want)
+    st = eng.Session(w, h, 3, win, "lk_float", min_det=5e9)
+    st.stream_begin()
+    got = {}
+    for f in frames:
+        d = st.stream_submit(f)
+        if d >= 1:
+            got[d] = [st.flow(k)[0].clone() for k in range(3)]
+    while True:
+        d = st.stream_drain()
+        if d == -2:
+            break
+        if d >= 1:
+            got[d] = [st.flow(k)[0].clone() for k in range(3)]
+    torch.cuda.synchronize()
+    for i in want:
+        for k in range(3):
+            assert_same(got[i][k].cpu().numpy(), want[i][k], f"guard on: stream pair {i} level {k}")
+    st.close()
