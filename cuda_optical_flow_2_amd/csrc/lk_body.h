@@ -37,12 +37,6 @@ struct LkTable {
 #ifndef OFX_LK_NT_STORES
 #define OFX_LK_NT_STORES 1
 #endif
-#ifndef OFX_LK_HBOX_LDS
-#define OFX_LK_HBOX_LDS 1 // the horizontal box sums' neighbour terms through LDS (HboxLds) instead of DPP adds (hbox4)
-#endif
-#ifndef OFX_LK_HBOX_OVERLAP
-#define OFX_LK_HBOX_OVERLAP 0 // 1: two quantities in flight (24 more live VGPRs: spills in the stream kernel)
-#endif
 #ifndef OFX_LK_PROGRESS_PRIORITY
 #define OFX_LK_PROGRESS_PRIORITY 1
 #endif
@@ -253,98 +247,6 @@ __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
     out[2] = hbox_one<R, 2>(q, s);
     out[3] = hbox_one<R, 3>(q, s);
 }
-
-// ---- the same box sum with the neighbour terms fetched through LDS ---------------------------------------------------------
-// hbox4 above takes every term that lies in another lane through a DPP add: 2 per output for R <= 4, i.e. 40 of the 65
-// instructions the five box sums of a row step cost (plus the wait states DPP operands need).  Here a lane publishes its
-// prefix sums q[0..3] and suffix sums s[0..3] with two 16-byte LDS writes and fetches the suffix array of every lane that
-// can reach it from the left and the prefix array of every lane on the right with one 16-byte read each; what is left
-// for the VALU are the in-lane prefix sums and one three-operand add per output and lane distance: 9 instructions per
-// quantity for R <= 4.  LDS instructions issue beside the VALU (the kernel has no other use for that port), a wave's LDS
-// operations execute in order, and the slots are private to the wave: no barrier, no fence.
-// Slot layout: `slot` = 64 x 16 B of prefix arrays, then (kHboxPad apart) 64 x 16 B of suffix arrays; the lanes next to the
-// wave's ends read the padding (their results are never stored).
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
-constexpr int kHboxPad = 64;                            // bytes of slack either side of an array: lanes -3 .. 66
-constexpr int kHboxArray = 1024 + 2 * kHboxPad;         // one array of a slot
-constexpr int kHboxSlot = 2 * kHboxArray;               // prefix + suffix
-constexpr int kLkWaveLds = 2 * kHboxSlot;               // two slots in rotation; the store exchange (below) reuses the first
-
-template <int R>
-struct HboxReach {
-    static constexpr int D = (R + 3) / 4; // lanes either side whose columns a window of radius R can touch
-};
-
-// term of output I (window columns I-R .. I+R, lane-relative) that lies in the lane K to the left, from its suffix array
-template <int R, int I, int K>
-__device__ __forceinline__ int hbox_lds_left(const i32x4 &sl)
-{
-    constexpr int lo = I - R; // lane -K holds relative columns -4K .. -4K+3
-    if constexpr (lo > -4 * K + 3) return 0;
-    else if constexpr (lo <= -4 * K) return sl[0];
-    else return sl[lo + 4 * K];
-}
-template <int R, int I, int K>
-__device__ __forceinline__ int hbox_lds_right(const i32x4 &pr)
-{
-    constexpr int hi = I + R; // lane +K holds relative columns 4K .. 4K+3
-    if constexpr (hi < 4 * K) return 0;
-    else if constexpr (hi >= 4 * K + 3) return pr[3];
-    else return pr[hi - 4 * K];
-}
-
-template <int R>
-struct HboxLds {
-    static constexpr int D = HboxReach<R>::D;
-    int own[4];
-    i32x4 sl[D], pr[D];
-
-    // publish this lane's prefix / suffix sums in `slot` and fetch the neighbours' (the reads are only waited for in finish)
-    __device__ __forceinline__ void start(const int (&a)[4], lds_ptr slot, int lane)
-    {
-        int q[4], s[4];
-        q[0] = a[0];
-        q[1] = q[0] + a[1];
-        q[2] = q[1] + a[2];
-        q[3] = q[2] + a[3];
-        s[3] = a[3];
-        s[2] = s[3] + a[2];
-        s[1] = s[2] + a[1];
-        s[0] = q[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int lo = i - R, hi = i + R;
-            const int olo = lo > 0 ? lo : 0, ohi = hi < 3 ? hi : 3;
-            own[i] = olo == 0 ? q[ohi] : (ohi == 3 ? s[olo] : q[ohi] - q[olo - 1]);
-        }
-        const lds_ptr pq = slot + kHboxPad + 16 * lane, ps = pq + kHboxArray;
-        *(__attribute__((address_space(3))) i32x4 *)pq = i32x4{q[0], q[1], q[2], q[3]};
-        *(__attribute__((address_space(3))) i32x4 *)ps = i32x4{s[0], s[1], s[2], s[3]};
-        asm volatile("" ::: "memory"); // (compiler ordering only: the hardware runs a wave's LDS operations in order)
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            sl[k] = *(__attribute__((address_space(3))) i32x4 *)(ps - 16 * (k + 1));
-            pr[k] = *(__attribute__((address_space(3))) i32x4 *)(pq + 16 * (k + 1));
-        }
-        asm volatile("" ::: "memory");
-    }
-    template <int I, int K>
-    __device__ __forceinline__ int terms(int acc) const
-    {
-        if constexpr (K > D) return acc;
-        else return terms<I, K + 1>(acc + hbox_lds_left<R, I, K>(sl[K - 1]) + hbox_lds_right<R, I, K>(pr[K - 1]));
-    }
-    __device__ __forceinline__ void finish(int (&out)[4]) const
-    {
-        out[0] = terms<0, 1>(own[0]);
-        out[1] = terms<1, 1>(own[1]);
-        out[2] = terms<2, 1>(own[2]);
-        out[3] = terms<3, 1>(own[3]);
-    }
-};
 
 // geometry of a wave tile for radius R (also used by the host)
 template <int R>
@@ -669,7 +571,8 @@ __device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&i
 // row (counted from the first valid byte) -- and both store instructions cover 1 KB without gaps, starting on the tile's
 // first output byte, which is 128-byte aligned whenever the level's row pitch is (every BASELINE level).  LDS instructions
 // issue beside the VALU, a wave's LDS operations execute in order, and the region is private to the wave: no barrier.
-static_assert(kLkWaveLds >= 2048 + 128, "the store exchange needs one row of a wave + the reads of the lanes past its valid end");
+constexpr int kLkWaveLds = 2048 + 128; // one row of a wave + the reads of the lanes past its valid end
+typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 
 // One wave of the fused level kernel: `wave` indexes the (level, tile, strip) work items of the table, `lane` is 0..63.
 // MAY_ACC: the launch may contain accumulating items (refinement iterations); false compiles that path out (the stream
@@ -734,6 +637,8 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
     const int x0 = tile * G::OUT_W;
     const int nv = min(x0 + G::OUT_W, A.w) - x0;
     uint32_t l16 = 16u * (uint32_t)lane;
+    const int lim = 8 * nv - 16, c16 = 16 * lane;
+    const bool st_lo4 = c16 <= lim, st_lo2 = c16 == lim + 8, st_hi4 = c16 <= lim - 1024, st_hi2 = c16 == lim + 8 - 1024;
     // LDS: lane l's 32 bytes go to offset 32 l; the tile's first output byte is lane LO_LANE's, so chunk c sits at 32 LO + 16 c
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
     const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
@@ -985,50 +890,18 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
 #endif
         int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
         float uv[8];
-        f32x4 xlo = {0.0f, 0.0f, 0.0f, 0.0f}, xhi = {0.0f, 0.0f, 0.0f, 0.0f}; // this lane's two chunks of the exchanged row
+        f32x4 xlo, xhi; // this lane's two chunks of the exchanged row (only defined, and only used, in emitting steps: the
+        asm("" : "=v"(xlo), "=v"(xhi)); // empty asm stands in for an initialisation that would cost 8 v_mov per step)
         if (emit) {
 #ifdef OFX_X_NOHBOX // timing experiments (OFX_BUILD_DEFS): what a stage costs is what the launch gains without it
 #pragma unroll
             for (int j = 0; j < 4; ++j) hxx[j] = vxx[j], hyy[j] = vyy[j], hxy[j] = vxy[j], hxt[j] = vxt[j], hyt[j] = vyt[j];
-#else
-#if OFX_LK_HBOX_LDS
-            {
-                // two slots in rotation: a quantity's arrays are published and its neighbours' fetched while the VALU finishes
-                // the quantity before it (in-order LDS: re-using a slot two quantities later needs no wait)
-                const lds_ptr slot0 = (lds_ptr)xlds, slot1 = slot0 + kHboxSlot;
-#if OFX_LK_HBOX_OVERLAP
-                HboxLds<R> b0, b1;
-                b0.start(vxx, slot0, lane);
-                b1.start(vyy, slot1, lane);
-                b0.finish(hxx);
-                b0.start(vxy, slot0, lane);
-                b1.finish(hyy);
-                b1.start(vxt, slot1, lane);
-                b0.finish(hxy);
-                b0.start(vyt, slot0, lane);
-                b1.finish(hxt);
-                b0.finish(hyt);
-#else
-                HboxLds<R> b;
-                b.start(vxx, slot0, lane);
-                b.finish(hxx);
-                b.start(vyy, slot1, lane);
-                b.finish(hyy);
-                b.start(vxy, slot0, lane);
-                b.finish(hxy);
-                b.start(vxt, slot1, lane);
-                b.finish(hxt);
-                b.start(vyt, slot0, lane);
-                b.finish(hyt);
-#endif
-            }
 #else
             hbox4<R>(vxx, hxx);
             hbox4<R>(vyy, hyy);
             hbox4<R>(vxy, hxy);
             hbox4<R>(vxt, hxt);
             hbox4<R>(vyt, hyt);
-#endif
 #endif
             if constexpr (!SUMS) {
                 // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
@@ -1080,15 +953,15 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
                 // 16 c == 8 nv - 8.  (The address is formed inside each branch: instruction selection only picks the
                 // scalar-base form when the offset's extension sits in the block of the access; it is only 8-byte aligned
                 // in general -- odd w*y.)
-                const int lim = 8 * nv - 16;
-                if ((int)l16 <= lim) {
+                // The four predicates are loop-invariant lane masks: computed once, applied as exec masks.
+                if (st_lo4) {
                     gstore_f32x4(gptr_f32_var(frow, l16), xlo);
-                } else if ((int)l16 == lim + 8) {
+                } else if (st_lo2) {
                     gstore_f32x2(gptr_f32_var(frow, l16), xlo.x, xlo.y);
                 }
-                if ((int)l16 <= lim - 1024) {
+                if (st_hi4) {
                     gstore_f32x4(gptr_f32_var(frow, l16) + 256, xhi);
-                } else if ((int)l16 == lim - 1016) {
+                } else if (st_hi2) {
                     gstore_f32x2(gptr_f32_var(frow, l16) + 256, xhi.x, xhi.y);
                 }
             }
