@@ -230,22 +230,58 @@ __device__ __forceinline__ int hbox_one(const int (&q)[4], const int (&s)[4])
     return hbox_left<R, I, 1>(s, hbox_right<R, I, 1>(q, own));
 }
 
+// the value of relative column C (any lane): C in 0..3 is this lane's a[C], C < 0 lies in the lane to the left, C > 3 to the right
+// x - (column C's value) and x + (column C's value) for |lane distance| <= 1, the DPP operand in the instruction's first
+// source (dst = dpp(src0) - src1 is v_sub_u32_dpp, the form hipcc folds correctly; the "rev" form is the one it gets wrong,
+// see lane_shift_right): a running value is kept negated every other step so that only that form occurs.
+template <int C>
+__device__ __forceinline__ int col_minus(const int (&a)[4], int y) // (column C) - y
+{
+    if constexpr (C >= 0 && C <= 3) {
+        return a[C] - y;
+    } else {
+        constexpr int idx = ((C % 4) + 4) % 4;
+        int r = __builtin_amdgcn_update_dpp(0, a[idx], C > 3 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - y;
+        asm volatile("" : "+v"(r));
+        return r;
+    }
+}
+
 template <int R>
 __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
 {
-    int q[4], s[4];
-    q[0] = a[0];
-    q[1] = q[0] + a[1];
-    q[2] = q[1] + a[2];
-    q[3] = q[2] + a[3];
-    s[3] = a[3];
-    s[2] = s[3] + a[2];
-    s[1] = s[2] + a[1];
-    s[0] = q[3];
-    out[0] = hbox_one<R, 0>(q, s);
-    out[1] = hbox_one<R, 1>(q, s);
-    out[2] = hbox_one<R, 2>(q, s);
-    out[3] = hbox_one<R, 3>(q, s);
+    if constexpr (R <= 4) {
+        // Windows of neighbouring columns differ by one column leaving and one entering, and for R <= 4 both lie in this lane
+        // or the one next to it: out[0] in full, then out[I+1] = out[I] - a(I - R) + a(I + R + 1), each difference two
+        // instructions -- n = a(I - R) - out[I]; out[I+1] = a(I + R + 1) - n -- 11 per quantity instead of 13.
+        int q[4], s[4];
+        q[0] = a[0];
+        q[1] = q[0] + a[1];
+        q[2] = q[1] + a[2];
+        q[3] = q[2] + a[3];
+        s[3] = a[3];
+        s[2] = s[3] + a[2];
+        s[1] = s[2] + a[1];
+        s[0] = q[3];
+        out[0] = hbox_one<R, 0>(q, s);
+        out[1] = col_minus<1 + R>(a, col_minus<0 - R>(a, out[0]));
+        out[2] = col_minus<2 + R>(a, col_minus<1 - R>(a, out[1]));
+        out[3] = col_minus<3 + R>(a, col_minus<2 - R>(a, out[2]));
+    } else {
+        int q[4], s[4];
+        q[0] = a[0];
+        q[1] = q[0] + a[1];
+        q[2] = q[1] + a[2];
+        q[3] = q[2] + a[3];
+        s[3] = a[3];
+        s[2] = s[3] + a[2];
+        s[1] = s[2] + a[1];
+        s[0] = q[3];
+        out[0] = hbox_one<R, 0>(q, s);
+        out[1] = hbox_one<R, 1>(q, s);
+        out[2] = hbox_one<R, 2>(q, s);
+        out[3] = hbox_one<R, 3>(q, s);
+    }
 }
 
 // geometry of a wave tile for radius R (also used by the host)
