@@ -694,6 +694,35 @@ def main():
                            "workload": f"{wa}x{ha}, {la} levels, window 19 (the reference's GPU constant), 3-channel host images in, "
                                        "host flow pyramid out, both pyramids rebuilt per pair as gpu::gauss_pyramid's signature demands"}
             extra["api_compat"] = api
+            # the front end of main.cu's frame (main.cu:232-240, in front of the pyramid): grayscale + the 9x9 bilateral
+            # pre-filter (sigma 2 / 10), device-resident, 3-channel images as the reference passes them.  Bytes per pixel
+            # (SURVEY 8d): grayscale 3 read + 3 written, bilateral 3 (src) + 3 (gray) read + 3 written.  The bilateral filter
+            # is bit-exact fp64 arithmetic in the reference's tap order (81 taps x ~16 double operations per pixel): it is
+            # compute-bound by that definition, the HBM fraction says how far.
+            from cuda_optical_flow_2_amd import lib as _l
+            L_ = _l.load()
+            fe = {}
+            for nm in ("1080p", "4k"):
+                wa, ha = WORKLOADS[nm][:2]
+                img = torch.randint(0, 256, (ha, wa, 3), dtype=torch.uint8, device="cuda")
+                gray, filt = torch.empty_like(img), torch.empty_like(img)
+                st_ = torch.cuda.current_stream().cuda_stream
+
+                def timed(fn, reps):
+                    fn(); torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        fn()
+                    e1.record(); torch.cuda.synchronize()
+                    return e0.elapsed_time(e1) / reps * 1e3
+                t_g = timed(lambda: _l.check(L_.ofx_grayscale_avg_3ch(img.data_ptr(), gray.data_ptr(), wa, ha, st_), "grayscale"), 20)
+                t_b = timed(lambda: _l.check(L_.ofx_bilateral_3ch(gray.data_ptr(), gray.data_ptr(), filt.data_ptr(), wa, ha, 9, 9, 2.0, 10.0, st_), "bilateral"), 5)
+                fe[nm] = {"grayscale_us": round(t_g, 1), "grayscale_frac": round(6 * wa * ha / (t_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "bilateral_9x9_us": round(t_b, 1), "bilateral_frac": round(9 * wa * ha / (t_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "value": round(wa * ha / ((t_g + t_b) * 1e-6) / 1e6, 1), "unit": "Mpix/s"}
+                del img, gray, filt
+            extra["frontend"] = fe
         if dt_indep is not None:
             ms4 = dt_indep / args.steps * 1e3
             extra["independent_pairs_per_rank"] = {

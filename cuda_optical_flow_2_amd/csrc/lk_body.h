@@ -37,6 +37,9 @@ struct LkTable {
 #ifndef OFX_LK_NT_STORES
 #define OFX_LK_NT_STORES 1
 #endif
+#ifndef OFX_LK_HBOX_SLIDE
+#define OFX_LK_HBOX_SLIDE 1
+#endif
 #ifndef OFX_LK_PROGRESS_PRIORITY
 #define OFX_LK_PROGRESS_PRIORITY 1
 #endif
@@ -250,10 +253,11 @@ __device__ __forceinline__ int col_minus(const int (&a)[4], int y) // (column C)
 template <int R>
 __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
 {
-    if constexpr (R <= 4) {
+    if constexpr (OFX_LK_HBOX_SLIDE && R <= 4) {
         // Windows of neighbouring columns differ by one column leaving and one entering, and for R <= 4 both lie in this lane
-        // or the one next to it: out[0] in full, then out[I+1] = out[I] - a(I - R) + a(I + R + 1), each difference two
-        // instructions -- n = a(I - R) - out[I]; out[I+1] = a(I + R + 1) - n -- 11 per quantity instead of 13.
+        // or the one next to it: out[0] and out[3] in full, then out[1] = out[0] - a(-R) + a(R + 1) and
+        // out[2] = out[3] - a(R + 3) + a(2 - R), each difference two instructions -- n = a(leaving) - out; out' = a(entering) - n
+        // -- two short dependent chains, 11-12 instructions per quantity instead of 13.
         int q[4], s[4];
         q[0] = a[0];
         q[1] = q[0] + a[1];
@@ -264,9 +268,9 @@ __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
         s[1] = s[2] + a[1];
         s[0] = q[3];
         out[0] = hbox_one<R, 0>(q, s);
+        out[3] = hbox_one<R, 3>(q, s);
         out[1] = col_minus<1 + R>(a, col_minus<0 - R>(a, out[0]));
-        out[2] = col_minus<2 + R>(a, col_minus<1 - R>(a, out[1]));
-        out[3] = col_minus<3 + R>(a, col_minus<2 - R>(a, out[2]));
+        out[2] = col_minus<2 - R>(a, col_minus<3 + R>(a, out[3]));
     } else {
         int q[4], s[4];
         q[0] = a[0];

@@ -1,22 +1,35 @@
+# Round evidence for profiles/: rocprofv3 kernel stats of the bench command (stream and plain path, iters = 5, compat_cpu) and
+# HBM traffic per launch from separate --pmc passes (FETCH_SIZE / WRITE_SIZE; never combined with tracing).
+#   gpurun -- 'bash tools/profile_round.sh r02'      then copy gpurun_out/prof_<tag>/summary/* into profiles/
 set -e
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof_l
-rm -rf $O; mkdir -p $O
+O=$R/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O/summary
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stream -- python bench.py --no-cpu-baseline --no-extras > $O/bench_stream.json 2> $O/stream.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/plain -- python bench.py --no-cpu-baseline --no-extras --path plain > $O/bench_plain.json 2> $O/plain.err
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_stream -- python tools/pmc_run.py 4k stream > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_stream -- python tools/pmc_run.py 4k stream > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_plain -- python tools/pmc_run.py 4k plain > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_plain -- python tools/pmc_run.py 4k plain > /dev/null 2>&1
-mkdir -p $O/pmc_stream $O/pmc_plain
-cp -r $O/pmc_fetch_stream $O/pmc_write_stream $O/pmc_stream/
-cp -r $O/pmc_fetch_plain $O/pmc_write_plain $O/pmc_plain/
-python tools/pmc_parse.py $O/pmc_stream stream_kernel 3 > $O/traffic_stream.json
-python tools/pmc_parse.py $O/pmc_plain lk_level_kernel 1 > $O/traffic_plain.json
-cat $O/traffic_stream.json $O/traffic_plain.json
-find $O -name "*kernel_stats.csv" | head
+stats() { # name, bench args...
+  n=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
+  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench4k_${n}_kernel_stats.csv
+  echo "== $n"; head -4 "$f"
+}
+stats stream
+stats plain --path plain
+stats iters5 --iters 5 --steps 200
+stats compat_cpu --mode compat_cpu
+pmc() { # name, kernel substring, skip, pmc_run args...
+  n=$1; k=$2; skip=$3; shift 3
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n/$C -- python tools/pmc_run.py "$@" > /dev/null 2> $O/pmc_${n}_$C.err
+  done
+  python tools/pmc_parse.py $O/pmc_$n $k $skip | tee -a $O/summary/${TAG}_traffic_pmc.jsonl
+}
+pmc stream stream_kernel 3 4k stream lk_float
+pmc plain lk_level_kernel 1 4k plain lk_float
+pmc compat stream_kernel 3 4k stream compat_cpu
+pmc iters5_lk lk_level_kernel 1 4k plain lk_float 5
+pmc iters5_warp warp_u8_kernel 1 4k plain lk_float 5
 # keep the merge small: drop the big traces
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +2M -delete
