@@ -169,12 +169,100 @@ __global__ __launch_bounds__(256) void solve_kernel(const T *sxx, const T *syy, 
 // The range weight depends only on the integer grey difference k in [-255,255], so the host evaluates
 // 1/(2 pi sB^2) * pow(e, -k^2/(2 sB^2)) with libm for k^2 of 0..255 -- the very expression the CPU path evaluates
 // per tap -- and the kernel looks it up: identical doubles, no transcendental on the device.
+//
+// The arithmetic is the reference's, operation for operation and in its tap order (row-major over the window, double
+// accumulators, (src * nb) * ns) -- that is what makes the output bit-identical, and it is what the kernel costs: 81 taps
+// of 7 (grey image) to 15 (colour) double-precision instructions per pixel at 9x9.  What the kernel removes is everything
+// else: a block stages its (64 + ww - 1) x (4 + wh - 1) neighbourhood in LDS once -- the grey value as a ready-made byte
+// offset into the range table, pixels outside the image as a sentinel whose offsets land on zero entries, so that skipped
+// taps become additions of +0.0 (exact no-ops on these non-negative sums) and the tap loop has no bounds tests -- the
+// range table sits in LDS as a function of the SIGNED difference (no abs), the spatial weights arrive as scalars, and a
+// block whose pixels all have three equal channels (main.cu:240 filters the grey image) accumulates one channel.
 constexpr int kMaxBilateral = 13;
 struct BilateralArg {
     double range[256];
     double spatial[kMaxBilateral * kMaxBilateral];
 };
 
+constexpr int kBilTileW = 64, kBilTileH = 4;
+constexpr int kBilSentinel = 1023;                 // grey "value" of a pixel outside the image
+constexpr int kBilLut = kBilSentinel + 255 + 1;    // entries: index = g - f0 + 255
+
+template <int WW>
+__global__ __launch_bounds__(256) void bilateral_tiled_kernel(const uint8_t *src3, const uint8_t *gray3, uint8_t *dst3, int w, int h, int wh,
+                                                              const BilateralArg B)
+{
+    constexpr int R = WW >> 1, TW = kBilTileW + 2 * R;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    double *lut = reinterpret_cast<double *>(smem);                                   // kBilLut doubles
+    uint32_t *spx = reinterpret_cast<uint32_t *>(smem + kBilLut * sizeof(double));    // [rows][TW]: s0 | s1 << 8 | s2 << 16
+    const int ry = wh >> 1, rows = kBilTileH + 2 * ry;
+    uint16_t *gof = reinterpret_cast<uint16_t *>(spx + (size_t)rows * TW);            // [rows][TW]: 8 * grey value (or sentinel)
+    const int tid = (int)threadIdx.x, x0 = (int)blockIdx.x * kBilTileW, y0 = (int)blockIdx.y * kBilTileH;
+
+    for (int i = tid; i < kBilLut; i += 256) {
+        const int d = i - 255; // signed grey difference
+        lut[i] = (d >= -255 && d <= 255) ? B.range[d < 0 ? -d : d] : 0.0;
+    }
+    int grey_only = 1;
+    for (int i = tid; i < rows * TW; i += 256) {
+        const int tx = x0 - R + i % TW, ty = y0 - ry + i / TW;
+        uint32_t px = 0u;
+        uint16_t go = (uint16_t)(8 * kBilSentinel);
+        if (tx >= 0 && tx < w && ty >= 0 && ty < h) {
+            const size_t q = 3 * ((size_t)ty * w + tx);
+            const uint32_t s0 = src3[q], s1 = src3[q + 1], s2 = src3[q + 2];
+            px = s0 | (s1 << 8) | (s2 << 16);
+            go = (uint16_t)(8 * (int)gray3[q]);
+            grey_only &= (s0 == s1 && s1 == s2) ? 1 : 0;
+        }
+        spx[i] = px;
+        gof[i] = go;
+    }
+    grey_only = __syncthreads_and(grey_only); // (also orders the tile and the table before the taps)
+
+    const int lx = tid & 63, ly = tid >> 6, x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) return;
+    // byte offset of table entry (g - f0 + 255) = gof - f0off, f0off = 8 * (f0 - 255)  (may be negative: signed arithmetic)
+    const int f0off = (int)gof[(ly + ry) * TW + lx + R] - 8 * 255;
+    const uint8_t *lut_b = reinterpret_cast<const uint8_t *>(lut);
+    double wsum = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (grey_only) {
+        for (int m = 0; m < wh; ++m) {
+            const uint32_t *prow = spx + (ly + m) * TW + lx;
+            const uint16_t *grow = gof + (ly + m) * TW + lx;
+#pragma unroll
+            for (int n = 0; n < WW; ++n) {
+                const double nb = *reinterpret_cast<const double *>(lut_b + ((int)grow[n] - f0off));
+                const double ns = B.spatial[m * WW + n];
+                wsum += nb * ns;
+                a0 += (double)(prow[n] & 0xffu) * nb * ns;
+            }
+        }
+        a1 = a2 = a0;
+    } else {
+        for (int m = 0; m < wh; ++m) {
+            const uint32_t *prow = spx + (ly + m) * TW + lx;
+            const uint16_t *grow = gof + (ly + m) * TW + lx;
+#pragma unroll
+            for (int n = 0; n < WW; ++n) {
+                const double nb = *reinterpret_cast<const double *>(lut_b + ((int)grow[n] - f0off));
+                const double ns = B.spatial[m * WW + n];
+                const uint32_t px = prow[n];
+                wsum += nb * ns;
+                a0 += (double)(px & 0xffu) * nb * ns;
+                a1 += (double)((px >> 8) & 0xffu) * nb * ns;
+                a2 += (double)((px >> 16) & 0xffu) * nb * ns;
+            }
+        }
+    }
+    uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+    d[0] = (uint8_t)(int)(a0 / wsum);
+    d[1] = (uint8_t)(int)(a1 / wsum);
+    d[2] = (uint8_t)(int)(a2 / wsum);
+}
+
+// any window the tiled kernel is not instantiated for: one thread per pixel, taps tested one by one
 __global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t *src3, const uint8_t *gray3, uint8_t *dst3, int w, int h,
                                                         int ww, int wh, const BilateralArg B)
 {
@@ -204,6 +292,18 @@ __global__ __launch_bounds__(256) void bilateral_kernel(const uint8_t *src3, con
     d[0] = (uint8_t)(int)(acc[0] / wsum);
     d[1] = (uint8_t)(int)(acc[1] / wsum);
     d[2] = (uint8_t)(int)(acc[2] / wsum);
+}
+
+template <int WW>
+int launch_bilateral_tiled(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int wh, const BilateralArg &B,
+                           hipStream_t st)
+{
+    const int rows = kBilTileH + 2 * (wh >> 1), tw = kBilTileW + 2 * (WW >> 1);
+    const size_t lds = (size_t)kBilLut * sizeof(double) + (size_t)rows * tw * (sizeof(uint32_t) + sizeof(uint16_t)) + 16;
+    hipLaunchKernelGGL(bilateral_tiled_kernel<WW>, dim3(ofx_div_up(w, kBilTileW), ofx_div_up(h, kBilTileH)), dim3(256), lds, st, d_src3,
+                       d_gray3, d_dst3, w, h, wh, B);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
 }
 
 // ---- the remaining functions of namespace cpu (OptFlowCpu.hpp), so that the cpu:: call surface runs on the device too ------
@@ -452,7 +552,19 @@ extern "C" int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, 
         const double kk = (double)k * (double)k;
         B.range[k] = 1.0 / (2.0 * M_PI * sb2) * pow(M_E, -0.5 * (kk) / sb2);
     }
-    hipLaunchKernelGGL(bilateral_kernel, grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_src3, d_gray3, d_dst3, w, h, ww, wh, B);
+    hipStream_t st = ofx_stream(stream);
+    if (wh == ww || (wh & 1)) { // (the tiled kernel centres the rows on wh / 2 like the reference; any wh <= ww works)
+        switch (ww) {
+        case 3: return launch_bilateral_tiled<3>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        case 5: return launch_bilateral_tiled<5>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        case 7: return launch_bilateral_tiled<7>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        case 9: return launch_bilateral_tiled<9>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        case 11: return launch_bilateral_tiled<11>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        case 13: return launch_bilateral_tiled<13>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);
+        default: break;
+        }
+    }
+    hipLaunchKernelGGL(bilateral_kernel, grid2d(w, h), dim3(256), 0, st, d_src3, d_gray3, d_dst3, w, h, ww, wh, B);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }

@@ -191,3 +191,18 @@ def test_replay_of_main_cu_frame_loop(oracle, tmp_path):
         assert_same(got[f - 1], oracle.compose_flow(flow, levels, 0), f"replay frame {f}: composed level-0 field")
         prev_pyr = pyr
     assert r.stdout.count("fnv") == nf
+
+
+@pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (130, 131)])
+def test_bilateral_filter_tiled_kernel_matches_oracle(gpu, cpu, oracle, size):
+    """The tiled bilateral kernel (LDS neighbourhood, range table by signed difference, out-of-image taps as +0.0) is the
+    reference's arithmetic in the reference's order: bit-exact against the oracle on sizes that are not multiples of the
+    64 x 4 tile, windows 9x9 / 5x5 / 7x3 / 13x13, a colour image (three channels accumulated) and a grey one (one)."""
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h)
+    colour = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    grey = oracle.grayscale_avg(colour)
+    for (ww, wh, ss, sb) in ((9, 9, 2.0, 10.0), (5, 5, 1.5, 20.0), (7, 3, 1.0, 5.0), (13, 13, 3.0, 40.0)):
+        assert_same(gpu.bilinear_filter(grey, grey, ww, wh, ss, sb), oracle.bilateral_3ch(grey, grey, ww, wh, ss, sb), f"grey {ww}x{wh} at {w}x{h}")
+        assert_same(gpu.bilinear_filter(colour, grey, ww, wh, ss, sb), oracle.bilateral_3ch(colour, grey, ww, wh, ss, sb), f"colour {ww}x{wh} at {w}x{h}")
+    assert_same(cpu.bilinear_filter_3ch(colour, grey, 9, 9, 2.0, 10.0), oracle.bilateral_3ch(colour, grey, 9, 9, 2.0, 10.0), "cpu:: twin")
