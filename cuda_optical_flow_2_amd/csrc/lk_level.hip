@@ -67,9 +67,9 @@ unsigned long long *g_stream_trace = nullptr; // tools/stream_timeline.py
 int g_stream_trace_blocks = 0;
 int g_trace_header[kPyrStages + 1] = {0};
 
-// lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu would spill there
+// lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu needs ~120: 4 blocks (<= 128)
 #ifndef OFX_STREAM_MIN_BLOCKS
-#define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 3)
+#define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 4)
 #endif
 template <int R, int MODE, bool FAST>
 __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
