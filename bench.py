@@ -234,7 +234,7 @@ def main():
         return (3 * max(batch, 4) + 4 + 3) // 4 * 4
 
     # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
-    # hand them over: long enough for ofx_params.borrow_frames (a buffer stays untouched for 3 * batch further submits), and
+    # hand them over: long enough for ofx_params.borrow_frames (frame f's buffer is read until the launch of submit f + 3 * batch), and
     # large enough that a frame is not still sitting in the 256 MB Infinity Cache when it comes round again (four buffers
     # would be: with borrowed frames that alone made the LK stage ~10 % faster).  Contents repeat every four buffers.
     ring_n = int(os.environ.get("OFX_BENCH_RING", "0")) or ring_size(args.batch)  # (experiments: other ring sizes)

@@ -10,10 +10,12 @@
 //   * the wave marches DOWN a strip of rows.  Per step it loads one new row of each image, forms the three
 //     derivative values of its 4 columns (left/right neighbour columns come from the adjacent lanes through
 //     DPP wave shifts, no LDS), and updates 5 x 4 vertical running sums:  V += P(row entering) - P(row leaving).
-//     The leaving row's derivatives come back from a lane-private LDS ring (no barriers: a lane only ever
-//     reads what it wrote).
+//     The leaving row's derivatives are recomputed from the image (its rows are L2-resident) in the high halves of the
+//     same packed-int16 instructions that compute the entering row's (lk_body.h).
 //   * the horizontal half of the box sum is done in registers: in-lane prefix/suffix sums plus whole-lane totals
-//     of the neighbouring lanes, again through DPP.
+//     of the neighbouring lanes, again through DPP (a sliding difference per output for windows up to 9x9).
+//   * the only use of LDS: each output row is exchanged through it so that both streaming store instructions cover
+//     gap-free 128-byte lines (non-temporal stores of 16-byte pieces run at half the write bandwidth).
 //   * all sums are exact int32, so results do not depend on strip/tile/shard boundaries.
 //   * window radius R and mode are template parameters; the host dispatches.
 //

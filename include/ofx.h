@@ -326,11 +326,15 @@ typedef struct ofx_params {
      * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
     /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame
-     * buffers handed to ofx_session_stream_submit, and the pyramid stage only writes levels 1 and up.  The caller must
-     * then keep every submitted frame buffer valid AND UNMODIFIED until the flow of the pair that starts at that frame
-     * has been reported complete, i.e. for 3 * stream_batch further submits (a ring of capture / decoder surfaces).
-     * Saves 2 bytes per level-0 pixel of HBM traffic per frame (at 4K: 13 % of a four-frame tick, most of it the
-     * write-back of the copy's dirty lines between launches).  0 = copy (any buffer lifetime). */
+     * buffers handed to ofx_session_stream_submit, and the pyramid stage only writes levels 1 and up.
+     * LIFETIME RULE (the one statement of it; INTEGRATION.md, DESIGN.md and engine.py quote it): the buffer of frame f
+     * (frames counted from 0, B = stream_batch) is last read by the launch that the submit of frame f + 3B enqueues, at the
+     * latest.  It may be rewritten (a) by work enqueued on the SAME stream after that submit call, or (b) from the host or
+     * another stream once that launch has COMPLETED -- the submit call returning is not enough.  A producer that writes
+     * frame g into its buffer on the stream, right before submitting it, therefore needs a ring of at least 3B + 1
+     * buffers; one that writes asynchronously needs as many more as it has launches in flight.
+     * Saves 2 bytes per level-0 pixel of HBM traffic per frame and a third of the pipeline's cache working set
+     * (DESIGN.md section 4.3).  0 = copy (any buffer lifetime). */
     int borrow_frames;
     /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */
     float min_det;
