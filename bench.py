@@ -636,6 +636,39 @@ def main():
                              "frac": round(pair_alg / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "launches": launches,
                              "timed_in": "second pass, hipEventRecord around every launch of the pair"}}
             s2.close()
+            # the same configuration through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every
+            # further iteration one warp + one accumulating LK launch over all levels of all B pairs (taller strips, 2 + 2 *
+            # (iters - 1) launches per B pairs instead of 3 + 2 * iters per pair); frames copied into the session
+            b9 = 4 if 4 * levels <= 40 else 2
+            s9 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it, stream_batch=b9)
+            s9.stream_begin()
+            fd9 = StreamFeed(s9.stream_submit_frames, d_ring, b9)
+            for _ in range(4 * b9):
+                fd9.step()
+            torch.cuda.synchronize()
+            n9 = max(4 * b9, min(args.steps, 48) // b9 * b9)
+            t0 = time.perf_counter()
+            for _ in range(n9):
+                fd9.step()
+            torch.cuda.synchronize()
+            ms9 = (time.perf_counter() - t0) / n9 * 1e3
+            s9.timing((n9 // b9) * (2 * it + 3))
+            for _ in range(n9):
+                fd9.step()
+            torch.cuda.synchronize()
+            k9 = {k: s9.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
+            s9.timing(0)
+            s9.close()
+            us9 = sum(v[0] * v[2] for v in k9.values() if v[2]) / n9            # kernel time per pair
+            pair_alg9 = pair_alg                                                # same algorithmic bytes per pair
+            streamed = {
+                "workload": f"as above through the stream pipeline, {b9} pairs per launch, frames copied into the session",
+                "value": round(w * h / (ms9 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms9, 5), "steps": n9,
+                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_pair": pair_alg9,
+                             "kernel_us_per_pair": round(us9, 2), "achieved": round(pair_alg9 / (us9 * 1e-6) / 1e9, 1),
+                             "frac": round(pair_alg9 / (us9 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                             "launches": {k: {"avg_us": round(v[0], 2), "per_tick": v[2] // (n9 // b9)} for k, v in k9.items() if v[2]}}}
+            extra["baseline_config_with_iters"]["streamed"] = streamed
             if args.path == "stream" and args.borrow:
                 # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
                 # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it

@@ -326,7 +326,7 @@ extern "C" int ofx_shift_vector(const float *const *d_flow_levels, int level, in
 
 int ofx_shift_table(const ofx_shift_desc *levels, int n, ShiftTable *out, int *blocks_out)
 {
-    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_shift_levels: bad descriptor count %d", n);
+    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LK_ITEMS, "ofx_shift_levels: bad descriptor count %d", n);
     ShiftTable t{};
     int blocks = 0, m = 0;
     for (int i = 0; i < n; ++i) {
@@ -370,7 +370,7 @@ extern "C" int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geo
 
 extern "C" int ofx_warp_levels(const ofx_warp_desc *levels, int n, void *stream)
 {
-    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LEVELS, "ofx_warp_levels: bad descriptor count %d", n);
+    OFX_REQUIRE(levels && n >= 1 && n <= OFX_MAX_LK_ITEMS, "ofx_warp_levels: bad descriptor count %d", n);
     WarpTable t{};
     int blocks = 0, m = 0;
     for (int i = 0; i < n; ++i) {

@@ -32,6 +32,8 @@ struct ofx_session {
     // that the pipelined path can build frame i+1's pyramid / corner / shift while pair i's LK launch is running
     uint8_t *img[kSets][OFX_MAX_LEVELS]{};              // see kSets
     uint8_t *sh[2][OFX_MAX_LEVELS]{};
+    // refinement iterations in the stream pipeline: per flow set (pair p -> set p mod B) the shifted and the warped next image
+    uint8_t *itsh[kMaxBatch][2][OFX_MAX_LEVELS]{};
     int cur = 0, sht = 0;                               // img[cur] = previous frame, img[(cur+1)%3] = next frame
     uint8_t *plane[3][OFX_MAX_LEVELS]{};                // role view: 0 prev, 1 next, 2 shifted scratch
     hipStream_t aux = nullptr;                          // pipelined path: staging stream owned by the session
@@ -142,7 +144,9 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     const int n_sets = 3 * (p->stream_batch >= 2 ? p->stream_batch : 1) + 2;
     s->n_sets = n_sets;
     size_t total = 0;
-    std::vector<size_t> off_plane[kSets + 2], off_flow, off_flow2, flow_stride;
+    // (streamed refinement iterations: two more scratch planes per pair of a tick)
+    const int n_iter_sets = (p->iters > 1 && !p->sharded) ? 2 * (p->stream_batch >= 2 ? p->stream_batch : 1) : 0;
+    std::vector<size_t> off_plane[kSets + 2 + 2 * kMaxBatch], off_flow, off_flow2, flow_stride;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
         s->h[k] = p->height >> k;
@@ -170,7 +174,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
-        for (int t = 0; t < n_sets + 2; ++t) { // image sets + 2 shifted sets
+        for (int t = 0; t < n_sets + 2 + n_iter_sets; ++t) { // image sets + 2 shifted sets + the streamed iterations' scratch
             off_plane[t].push_back(total);
             total += plane_bytes;
         }
@@ -233,6 +237,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     for (int k = 0; k < p->levels; ++k) {
         for (int t = 0; t < n_sets; ++t) s->img[t][k] = base + off_plane[t][k];
         for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[n_sets + t][k];
+        for (int t = 0; t < n_iter_sets; ++t) s->itsh[t / 2][t % 2][k] = base + off_plane[n_sets + 2 + t][k];
         s->flowset[0][k] = reinterpret_cast<float *>(base + off_flow[k]);
         for (int t = 1; t < kMaxBatch; ++t)
             s->flowset[t][k] = reinterpret_cast<float *>(base + (t < p->stream_batch ? off_flow2[k] + (size_t)(t - 1) * flow_stride[k] : off_flow[k]));
@@ -818,6 +823,37 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         OFX_TRY(timed_launch(s, OFX_TIME_STREAM, stream, [&] { return ofx_stream_launch(&g, s->p.window, s->p.mode, stream); }));
     else
         OFX_TRY(ofx_stream_launch(&g, s->p.window, s->p.mode, stream));
+    // Extension (lk_iter): the tick's LK stage was iteration 1 of its pairs.  Every further iteration is
+    // one warp launch and one accumulating LK launch over ALL levels of ALL those pairs (B x levels items: the strips are B
+    // times as tall as in the pair-at-a-time path), after one launch that materialises the globally shifted next images the
+    // warp reads.  Same arithmetic, same bits as ofx_session_run_flow with iters > 1.
+    if (s->p.iters > 1 && newest >= 1) {
+        static thread_local ofx_shift_desc sd[OFX_MAX_LK_ITEMS];
+        static thread_local ofx_warp_desc wd[OFX_MAX_LK_ITEMS];
+        static thread_local ofx_lk_desc ld[OFX_MAX_LK_ITEMS];
+        int ns = 0, nw = 0;
+        for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) {
+            if (pl < 1 || pl > last_frame) continue;
+            const int b = (int)(pl % B);
+            for (int k = L - 1; k >= 0; --k) {
+                const ofx_geom g = level_geom(s, k, 0, s->h[k]);
+                const uint8_t *next_k = s->img[set_of(pl)][k];
+                const uint8_t *src = next_k;
+                if (k != L - 1) {
+                    sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], g, uvslot(pl) + 2 * k};
+                    src = s->itsh[b][0][k];
+                }
+                wd[nw] = ofx_warp_desc{src, s->itsh[b][1][k], g, s->flowset[b][k], 0, OFX_ITER_SCALE};
+                ld[nw] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->itsh[b][1][k], g, s->flowset[b][k], 0, nullptr, 1, s->p.min_det};
+                ++nw;
+            }
+        }
+        if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
+        for (int it = 1; it < s->p.iters; ++it) {
+            OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nw, stream); }));
+            OFX_TRY(timed_launch(s, OFX_TIME_LK_ACC, stream, [&] { return ofx_lk_levels(ld, nw, s->p.window, s->p.mode, stream); }));
+        }
+    }
     s->stream_n = f0 + B;
     return OFX_OK;
 }
@@ -829,7 +865,9 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
                 "ofx_session_stream_begin: on a sharded session the stream pipeline needs local_corner (the corner flows "
                 "computed from each frame's top-left patch); otherwise drive the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
-    OFX_REQUIRE(s->p.iters <= 1, "ofx_session_stream_begin: refinement iterations run through the pair-at-a-time paths");
+    OFX_REQUIRE(s->p.iters <= 1 || (!s->p.sharded && !s->p.borrow_frames),
+                "ofx_session_stream_begin: refinement iterations in the stream pipeline need an unsharded session that copies "
+                "its frames (borrow_frames = 0: the shift and warp launches address every plane with the session's pitch)");
     // staging work of the pair-at-a-time pipelined path may still be in flight on the session's own stream; the stream
     // pipeline is about to reuse the same image sets from the caller's stream
     if (s->aux) OFX_HIP(hipStreamSynchronize(s->aux));

@@ -293,9 +293,9 @@ struct ShiftArgs {
     int w, h, pitch, row0, row_end, out_y0, out_y1, blocks_x;
 };
 
-struct ShiftTable {
-    ShiftArgs lv[OFX_MAX_LEVELS];
-    int first_block[OFX_MAX_LEVELS + 1];
+struct ShiftTable { // (level, pair) items: up to the levels of every pair of a stream tick
+    ShiftArgs lv[OFX_MAX_LK_ITEMS];
+    int first_block[OFX_MAX_LK_ITEMS + 1];
     int n;
 };
 
@@ -365,8 +365,8 @@ struct WarpArgs {
 };
 
 struct WarpTable {
-    WarpArgs lv[OFX_MAX_LEVELS];
-    int first_block[OFX_MAX_LEVELS + 1];
+    WarpArgs lv[OFX_MAX_LK_ITEMS];
+    int first_block[OFX_MAX_LK_ITEMS + 1];
     int n;
 };
 

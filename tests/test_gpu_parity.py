@@ -1051,3 +1051,53 @@ def test_determinant_guard(eng, oracle):
         for k in range(3):
             assert_same(got[i][k].cpu().numpy(), want[i][k], f"guard on: stream pair {i} level {k}")
     st.close()
+
+
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 1), (640, 480, 4, 7, 5, 2), (1280, 720, 4, 9, 2, 4), (250, 186, 2, 5, 4, 8)])
+def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg):
+    """iters > 1 through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every further iteration is
+    ONE warp launch and ONE accumulating LK launch over all levels of all B pairs.  Same arithmetic as ofx_session_run_flow
+    with iters > 1 (itself bit-exact against the oracle's orc_lk_iter_level): every pair, every level, bit for bit; also for a
+    frame count that leaves a partial tick to the drain."""
+    import torch
+
+    w, h, L, win, iters, B = cfg
+    nf = 2 * B + 3
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.2 * i, -0.7 * i, seed=19)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, "lk_float", iters=iters)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B)
+    s.stream_begin()
+    got, seen = {}, 0
+
+    def snap(done):
+        nonlocal seen
+        if done >= 1:
+            for p in range(max(seen + 1, done - B + 1), done + 1):
+                got[p] = [s.flow_of(p, k)[0].clone() for k in range(L)]
+            seen = done
+    for f in frames:
+        snap(s.stream_submit(f))
+    while True:
+        d = s.stream_drain()
+        if d == -2:
+            break
+        snap(d)
+    torch.cuda.synchronize()
+    assert sorted(got) == list(range(1, nf))
+    for p in range(1, nf):
+        for k in range(L):
+            assert_same(got[p][k].cpu().numpy(), want[p][k], f"iters={iters} B={B}: pair {p} level {k}")
+    s.close()
+    from cuda_optical_flow_2_amd.lib import OfxError
+    bad = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B, borrow_frames=True)
+    with pytest.raises(OfxError):
+        bad.stream_begin()      # streamed iterations address every plane with the session's pitch: no borrowed frames
+    bad.close()
