@@ -638,9 +638,9 @@ def main():
             s2.close()
             # the same configuration through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every
             # further iteration one warp + one accumulating LK launch over all levels of all B pairs (taller strips, 2 + 2 *
-            # (iters - 1) launches per B pairs instead of 3 + 2 * iters per pair); frames copied into the session
+            # (iters - 1) launches per B pairs instead of 3 + 2 * iters per pair); frames read in place like the headline's
             b9 = 4 if 4 * levels <= 40 else 2
-            s9 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it, stream_batch=b9)
+            s9 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it, stream_batch=b9, borrow_frames=args.borrow)
             s9.stream_begin()
             fd9 = StreamFeed(s9.stream_submit_frames, d_ring, b9)
             for _ in range(4 * b9):
@@ -662,7 +662,7 @@ def main():
             us9 = sum(v[0] * v[2] for v in k9.values() if v[2]) / n9            # kernel time per pair
             pair_alg9 = pair_alg                                                # same algorithmic bytes per pair
             streamed = {
-                "workload": f"as above through the stream pipeline, {b9} pairs per launch, frames copied into the session",
+                "workload": f"as above through the stream pipeline, {b9} pairs per launch, frames " + ("read in place" if args.borrow else "copied"),
                 "value": round(w * h / (ms9 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms9, 5), "steps": n9,
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_pair": pair_alg9,
                              "kernel_us_per_pair": round(us9, 2), "achieved": round(pair_alg9 / (us9 * 1e-6) / 1e9, 1),

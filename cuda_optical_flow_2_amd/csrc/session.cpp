@@ -835,16 +835,21 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) {
             if (pl < 1 || pl > last_frame) continue;
             const int b = (int)(pl % B);
+            // (a borrowed level 0 is read in place here too; the launches below address a level's planes -- the caller's frame,
+            // the shifted and the warped image -- with ONE pitch, so borrowed frames must have the session's)
+            OFX_REQUIRE(!s->p.borrow_frames || (pitch_of(pl, 0, false) == s->pitch[0] && pitch_of(pl - 1, 0, false) == s->pitch[0]),
+                        "ofx_session_stream_submit: with refinement iterations borrowed frames need a row pitch of %d bytes (the width "
+                        "rounded up to 64), got %d", s->pitch[0], pitch_of(pl, 0, false));
             for (int k = L - 1; k >= 0; --k) {
                 const ofx_geom g = level_geom(s, k, 0, s->h[k]);
-                const uint8_t *next_k = s->img[set_of(pl)][k];
+                const uint8_t *next_k = plane_of(pl, k);
                 const uint8_t *src = next_k;
                 if (k != L - 1) {
                     sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], g, uvslot(pl) + 2 * k};
                     src = s->itsh[b][0][k];
                 }
                 wd[nw] = ofx_warp_desc{src, s->itsh[b][1][k], g, s->flowset[b][k], 0, OFX_ITER_SCALE};
-                ld[nw] = ofx_lk_desc{s->img[set_of(pl - 1)][k], s->itsh[b][1][k], g, s->flowset[b][k], 0, nullptr, 1, s->p.min_det};
+                ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][1][k], g, s->flowset[b][k], 0, nullptr, 1, s->p.min_det};
                 ++nw;
             }
         }
@@ -865,9 +870,7 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
                 "ofx_session_stream_begin: on a sharded session the stream pipeline needs local_corner (the corner flows "
                 "computed from each frame's top-left patch); otherwise drive the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
-    OFX_REQUIRE(s->p.iters <= 1 || (!s->p.sharded && !s->p.borrow_frames),
-                "ofx_session_stream_begin: refinement iterations in the stream pipeline need an unsharded session that copies "
-                "its frames (borrow_frames = 0: the shift and warp launches address every plane with the session's pitch)");
+    OFX_REQUIRE(s->p.iters <= 1 || !s->p.sharded, "ofx_session_stream_begin: refinement iterations need an unsharded session");
     // staging work of the pair-at-a-time pipelined path may still be in flight on the session's own stream; the stream
     // pipeline is about to reuse the same image sets from the caller's stream
     if (s->aux) OFX_HIP(hipStreamSynchronize(s->aux));

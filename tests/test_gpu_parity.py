@@ -1053,8 +1053,9 @@ def test_determinant_guard(eng, oracle):
     st.close()
 
 
-@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 1), (640, 480, 4, 7, 5, 2), (1280, 720, 4, 9, 2, 4), (250, 186, 2, 5, 4, 8)])
-def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg):
+@pytest.mark.parametrize("borrow", [False, True])
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 1), (640, 480, 4, 7, 5, 2), (1280, 720, 4, 9, 2, 4), (256, 192, 2, 5, 4, 8)])
+def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg, borrow):
     """iters > 1 through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every further iteration is
     ONE warp launch and ONE accumulating LK launch over all levels of all B pairs.  Same arithmetic as ofx_session_run_flow
     with iters > 1 (itself bit-exact against the oracle's orc_lk_iter_level): every pair, every level, bit for bit; also for a
@@ -1073,7 +1074,7 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg):
         want[i] = [plain.flow_host(k) for k in range(L)]
         plain.swap()
     plain.close()
-    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B)
+    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B, borrow_frames=borrow)
     s.stream_begin()
     got, seen = {}, 0
 
@@ -1083,7 +1084,7 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg):
             for p in range(max(seen + 1, done - B + 1), done + 1):
                 got[p] = [s.flow_of(p, k)[0].clone() for k in range(L)]
             seen = done
-    for f in frames:
+    for f in frames:   # (every frame its own buffer, pitch = width = a multiple of 64: what borrowed frames need here)
         snap(s.stream_submit(f))
     while True:
         d = s.stream_drain()
@@ -1096,8 +1097,12 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg):
         for k in range(L):
             assert_same(got[p][k].cpu().numpy(), want[p][k], f"iters={iters} B={B}: pair {p} level {k}")
     s.close()
-    from cuda_optical_flow_2_amd.lib import OfxError
-    bad = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B, borrow_frames=True)
-    with pytest.raises(OfxError):
-        bad.stream_begin()      # streamed iterations address every plane with the session's pitch: no borrowed frames
-    bad.close()
+    if borrow:
+        from cuda_optical_flow_2_amd.lib import OfxError
+        bad = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=1, borrow_frames=True)
+        bad.stream_begin()
+        padded = [torch.zeros((h, w + 64), dtype=torch.uint8, device="cuda")[:, :w] for _ in range(4)]
+        with pytest.raises(OfxError):   # the launches of an iteration address a level's planes with one pitch: the session's
+            for f in padded:
+                bad.stream_submit(f)
+        bad.close()
