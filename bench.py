@@ -348,8 +348,10 @@ def main():
     dt = time.perf_counter() - t0
     # pass 2 -- the dominant kernel's duration: the same steps again with a pair of HIP events recorded around every
     # launch on the stream it runs on (two extra packets per launch, so this pass is not the one timed above)
-    sess.timing(args.steps * (2 * max(1, args.iters) + 3))
-    for i in range(args.steps):
+    # (at least 400 steps, so that a short driver run -- K = 20 is five launches -- still averages over ~100 launches)
+    roof_steps = max(args.steps, 400 // args.batch * args.batch)
+    sess.timing(roof_steps * (2 * max(1, args.iters) + 3))
+    for i in range(roof_steps):
         step(warmup_steps + args.steps + i)
     fence()
     kinds = {k: sess.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
@@ -398,7 +400,7 @@ def main():
             what = f"stream session (batch {args.batch}) pairs {checked}, all {levels} levels == plain sequence, bit for bit"
         else:
             # pair-at-a-time paths: the flow of the last timed pair against the reference's literal level-by-level sequence
-            last = warmup_steps + 2 * args.steps - 1
+            last = warmup_steps + args.steps + roof_steps - 1
             a, b = d_frames[last % nframes], d_frames[(last + 1) % nframes]
             if driver is None:
                 got = [sess.flow(k)[0] for k in range(levels)]
@@ -440,7 +442,7 @@ def main():
             for _ in range(16 * batch):
                 fd.step()
             torch.cuda.synchronize()
-        n = max(8 * batch, steps // batch * batch)
+        n = max(400 // batch * batch, steps // batch * batch)   # (a short driver run must not shrink the extras to a handful of launches)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):

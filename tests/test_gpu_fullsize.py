@@ -221,3 +221,51 @@ def test_literal_baseline_configs_with_iterations_match_oracle(eng, oracle, cfg)
     want = oracle.flow_pair_iter(p, n, L, win, iters)
     for k in range(L):
         assert_same(got[k], want[k], f"{w}x{h} iters={iters} level {k}")
+
+
+def test_config5_8k_eight_logical_ranks_and_streamed_iterations(eng, oracle):
+    """BASELINE config 5 (7680x4320, 6 levels, 15x15, 10 iterations, 8 GPUs) on the one device there is:
+    (1) the pair row-sharded over 8 logical ranks, every rank streaming its block with local corner flows (four frames per
+        launch: 8 x 6 levels would exceed the 40 items of a launch), put together == the unsharded plain sequence;
+    (2) its 10 refinement iterations through the stream pipeline == the pair-at-a-time path, every pair and level, bit for
+        bit (that path is tied to the oracle's orc_lk_iter_level at 1080p / 4K above and at small sizes with up to 5 levels
+        in test_gpu_parity.py; the oracle needs minutes for an 8K pair with 10 iterations);
+    (3) a 1/16-area crop of the same frames (1920x1088, the whole pipeline: 6 levels, 15x15, 10 iterations) against the
+        oracle."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win = 7680, 4320, 6, 15
+    nf = 7
+    frames = [synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1] for i in range(nf)]
+    d_frames = [torch.from_numpy(f).cuda() for f in frames]
+    want = _plain_sequence(eng, d_frames, w, h, L, win, "lk_float")
+    R, B = 8, 4
+    _, views = _ring(frames, w, h, 16, 0, 0)
+    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B,
+                         borrow_frames=True) for r in range(R)]
+    got = _run_stream(eng, ranks, views, frames, B, L, w)
+    for p in range(1, nf):
+        for k in range(L):
+            assert _same_bits(torch.cat([got[p][r][k] for r in range(R)], dim=0), want[p][k]), f"8K, 8 ranks: pair {p} level {k}"
+    for s in ranks:
+        assert s.corner_status() == 0
+        s.close()
+    del got, want, ranks
+
+    iters = 10
+    want = _plain_sequence(eng, d_frames[:4], w, h, L, win, "lk_float", iters=iters)
+    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=2)
+    got = _run_stream(eng, [s], [v for v in d_frames[:4]], frames[:4], 2, L, w)
+    s.close()
+    for p in range(1, 4):
+        for k in range(L):
+            assert _same_bits(got[p][0][k], want[p][k]), f"8K iters={iters}: streamed pair {p} level {k} != pair-at-a-time"
+    del got, want, d_frames
+
+    cw, ch = 1920, 1088   # (even at every level that is downsampled; 1080 >> 3 = 135 is not)
+    a, b = frames[0][:ch, :cw].copy(), frames[1][:ch, :cw].copy()
+    hip = eng.flow_pair(a, b, L, win, "lk_float", iters=iters)
+    ref = oracle.flow_pair_iter(a, b, L, win, iters)
+    for k in range(L):
+        assert_same(hip[k], ref[k], f"crop 1920x1088, 6 levels, 15x15, iters={iters}: level {k}")
