@@ -378,12 +378,12 @@ extern "C" int ofx_warp_levels(const ofx_warp_desc *levels, int n, void *stream)
         OFX_TRY(ofx_check_geom(g, "ofx_warp_levels"));
         OFX_REQUIRE(levels[i].d_src && levels[i].d_dst && levels[i].d_flow, "ofx_warp_levels: null pointer");
         OFX_REQUIRE(levels[i].d_src != levels[i].d_dst, "ofx_warp_levels: in-place warp is not supported");
-        OFX_REQUIRE(g->row0 == 0 && g->rows == g->h, "ofx_warp_levels: whole levels only (the warp may read any row)");
+        OFX_REQUIRE(g->out_y0 >= g->row0 && g->out_y1 <= g->row0 + g->rows, "ofx_warp_levels: output rows outside the planes");
         OFX_REQUIRE(levels[i].flow_row0 <= g->out_y0, "ofx_warp_levels: flow_row0 > out_y0");
         if (g->out_y1 <= g->out_y0) continue;
         const int bx = ofx_div_up(g->pitch / 4, 256);
         t.lv[m] = WarpArgs{levels[i].d_src, levels[i].d_dst, levels[i].d_flow, levels[i].scale, g->w, g->h, g->pitch, g->row0,
-                           g->out_y0, g->out_y1, levels[i].flow_row0, bx};
+                           g->out_y0, g->out_y1, levels[i].flow_row0, bx, g->row0 + g->rows, levels[i].d_status, levels[i].status_bit};
         t.first_block[m] = blocks;
         blocks += bx * (g->out_y1 - g->out_y0);
         ++m;

@@ -28,6 +28,11 @@ struct ofx_session {
     int own0[OFX_MAX_LEVELS]{}, own1[OFX_MAX_LEVELS]{}; // rows this rank computes
     int buf0[OFX_MAX_LEVELS]{}, buf1[OFX_MAX_LEVELS]{}; // rows the plane buffers hold
     int cmp0[OFX_MAX_LEVELS]{}, cmp1[OFX_MAX_LEVELS]{}; // rows this rank downsamples itself
+    // rows the flow buffers hold: the own rows, or -- sharded sessions with refinement iterations -- the own rows plus
+    // (radius + 1) * (iters - 1) either side: iteration j is computed on (radius + 1) * (iters - j) extra rows so that the
+    // warp of iteration j + 1 finds the flow of every row its LK stencils touch without asking a neighbour (stream_tick)
+    int fl0[OFX_MAX_LEVELS]{}, fl1[OFX_MAX_LEVELS]{};
+    size_t flow_own_offset(int k) const { return (size_t)(own0[k] - fl0[k]) * (size_t)w[k] * 2; } // floats from a flow set to the own rows
     // storage: three image sets rotate through the roles prev -> (free) -> next, two shifted-scratch sets alternate, so
     // that the pipelined path can build frame i+1's pyramid / corner / shift while pair i's LK launch is running
     uint8_t *img[kSets][OFX_MAX_LEVELS]{};              // see kSets
@@ -125,8 +130,9 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
                 "ofx_session_create: stream_batch %d (0, 1, 2, 4 or 8)", p->stream_batch);
     OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
                 p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
-    OFX_REQUIRE(p->iters <= 1 || (p->mode != OFX_MODE_COMPAT_CPU && !p->sharded),
-                "ofx_session_create: refinement iterations need mode lk_float and an unsharded session");
+    OFX_REQUIRE(p->iters <= 1 || p->mode != OFX_MODE_COMPAT_CPU, "ofx_session_create: refinement iterations need mode lk_float");
+    OFX_REQUIRE(p->iters <= 1 || !p->sharded || p->local_corner,
+                "ofx_session_create: refinement iterations on a sharded session run through the stream pipeline, which needs local_corner");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
                 "ofx_session_create: %d levels is too many for %dx%d", p->levels, p->width, p->height);
     for (int k = 0; k + 1 < p->levels; ++k)
@@ -145,7 +151,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->n_sets = n_sets;
     size_t total = 0;
     // (streamed refinement iterations: two more scratch planes per pair of a tick)
-    const int n_iter_sets = (p->iters > 1 && !p->sharded) ? 2 * (p->stream_batch >= 2 ? p->stream_batch : 1) : 0;
+    const int n_iter_sets = p->iters > 1 ? 2 * (p->stream_batch >= 2 ? p->stream_batch : 1) : 0;
     std::vector<size_t> off_plane[kSets + 2 + 2 * kMaxBatch], off_flow, off_flow2, flow_stride;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
@@ -173,13 +179,27 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->own0[k] = s->buf0[k] = s->cmp0[k] = 0;
             s->own1[k] = s->buf1[k] = s->cmp1[k] = s->h[k];
         }
+        s->fl0[k] = s->own0[k];
+        s->fl1[k] = s->own1[k];
+        if (p->sharded && p->iters > 1) {
+            const int reach = (p->window >> 1) + 1, ext = reach * (p->iters - 1);
+            s->fl0[k] = s->own0[k] - ext > 0 ? s->own0[k] - ext : 0;
+            s->fl1[k] = s->own1[k] + ext < s->h[k] ? s->own1[k] + ext : s->h[k];
+            const int lo = s->fl0[k] - reach > 0 ? s->fl0[k] - reach : 0, hi = s->fl1[k] + reach < s->h[k] ? s->fl1[k] + reach : s->h[k];
+            if (lo < s->buf0[k] || hi > s->buf1[k]) {
+                ofx_set_error("ofx_session_create: level %d: %d iterations need rows [%d,%d) in the buffers (own rows +- (radius + 1) * iters), "
+                              "they hold [%d,%d): plan the shard with its iterations (ShardPlan(iters=...))", k, p->iters, lo, hi, s->buf0[k], s->buf1[k]);
+                delete s;
+                return OFX_E_INVALID;
+            }
+        }
         const size_t plane_bytes = align_up((size_t)s->pitch[k] * (size_t)(s->buf1[k] - s->buf0[k]) + 64, kAlign);
         for (int t = 0; t < n_sets + 2 + n_iter_sets; ++t) { // image sets + 2 shifted sets + the streamed iterations' scratch
             off_plane[t].push_back(total);
             total += plane_bytes;
         }
         off_flow.push_back(total);
-        const size_t own_rows = (size_t)(s->own1[k] - s->own0[k]);
+        const size_t own_rows = (size_t)(s->fl1[k] - s->fl0[k]);
         const size_t flow_bytes = align_up((own_rows ? own_rows : 1) * (size_t)s->w[k] * 2 * sizeof(float), kAlign);
         total += flow_bytes;
         off_flow2.push_back(total); // further flow sets: a B-frame stream tick writes the flows of B pairs
@@ -466,6 +486,7 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
                                    k == L - 1 ? nullptr : uv + 2 * k, 0, s->p.min_det};
         return timed_lk_launch(s, lk, nl, stream);
     }
+    OFX_REQUIRE(!s->p.sharded, "refinement iterations on a sharded session run through the stream pipeline (ofx_session_stream_*)");
     // Extension (DESIGN.md "lk_iter"): iteration 1 is the reference level; every further iteration warps
     // the shifted next image by the flow so far (bilinear, rounded to u8) and adds the flow of (prev, warped).
     // sh[0] holds the globally shifted next image (the warp source), sh[1] the warped image.
@@ -483,7 +504,7 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
         ofx_warp_desc wd[OFX_MAX_LEVELS];
         nl = 0;
         for (int k = L - 1; k >= 0; --k) {
-            wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE};
+            wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE, nullptr, 0};
             lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1, s->p.min_det};
             ++nl;
         }
@@ -496,9 +517,9 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
 // per level: the image rows the LK stencils of this shard's own rows touch (before the shift) and the rows its buffers hold
 static void shard_reach(const ofx_session *s, int (*rows)[4])
 {
-    const int reach = s->p.window / 2 + 1; // the LK stencil of the own rows reaches radius + 1 rows beyond them
+    const int reach = s->p.window / 2 + 1; // the LK stencil of the rows it computes reaches radius + 1 rows beyond them
     for (int k = 0; k < s->p.levels; ++k) {
-        const int n0 = s->own0[k] - reach, n1 = s->own1[k] + reach;
+        const int n0 = s->fl0[k] - reach, n1 = s->fl1[k] + reach;
         rows[k][0] = n0 < 0 ? 0 : n0;
         rows[k][1] = n1 > s->h[k] ? s->h[k] : n1;
         rows[k][2] = s->buf0[k]; // (rows outside comp but inside buf are the caller's to fill: the halo exchange)
@@ -664,7 +685,7 @@ extern "C" int ofx_session_plane(ofx_session *s, int which, int level, uint8_t *
 extern "C" int ofx_session_flow(ofx_session *s, int level, float **d_ptr, int *row0, int *rows)
 {
     OFX_REQUIRE(s && level >= 0 && level < s->p.levels, "ofx_session_flow: bad arguments");
-    if (d_ptr) *d_ptr = s->flow[level];
+    if (d_ptr) *d_ptr = s->flow[level] + s->flow_own_offset(level);
     if (row0) *row0 = s->own0[level];
     if (rows) *rows = s->own1[level] - s->own0[level];
     return OFX_OK;
@@ -682,7 +703,7 @@ extern "C" int ofx_session_get_flow_host(ofx_session *s, int level, float *h_dst
     OFX_REQUIRE(s && h_dst && level >= 0 && level < s->p.levels, "ofx_session_get_flow_host: bad arguments");
     const size_t bytes = (size_t)(s->own1[level] - s->own0[level]) * (size_t)s->w[level] * 2 * sizeof(float);
     hipStream_t st = ofx_stream(stream);
-    OFX_HIP(hipMemcpyAsync(h_dst, s->flow[level], bytes, hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipMemcpyAsync(h_dst, s->flow[level] + s->flow_own_offset(level), bytes, hipMemcpyDeviceToHost, st));
     OFX_HIP(hipStreamSynchronize(st));
     return OFX_OK;
 }
@@ -797,9 +818,9 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         if (pl < 1 || pl > last_frame) continue;
         float *const *fl = s->flowset[pl % B];
         for (int k = L - 1; k >= 0; --k) {
-            ofx_geom lg = level_geom(s, k, s->own0[k], s->own1[k]);
+            ofx_geom lg = level_geom(s, k, s->fl0[k], s->fl1[k]); // (the own rows, unless iterations follow on a shard)
             lg.pitch = pitch_of(pl, k, false);
-            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->own0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0, s->p.min_det};
+            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->fl0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0, s->p.min_det};
         }
         newest = pl;
     }
@@ -831,30 +852,38 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         static thread_local ofx_shift_desc sd[OFX_MAX_LK_ITEMS];
         static thread_local ofx_warp_desc wd[OFX_MAX_LK_ITEMS];
         static thread_local ofx_lk_desc ld[OFX_MAX_LK_ITEMS];
-        int ns = 0, nw = 0;
-        for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) {
-            if (pl < 1 || pl > last_frame) continue;
-            const int b = (int)(pl % B);
-            // (a borrowed level 0 is read in place here too; the launches below address a level's planes -- the caller's frame,
-            // the shifted and the warped image -- with ONE pitch, so borrowed frames must have the session's)
-            OFX_REQUIRE(!s->p.borrow_frames || (pitch_of(pl, 0, false) == s->pitch[0] && pitch_of(pl - 1, 0, false) == s->pitch[0]),
-                        "ofx_session_stream_submit: with refinement iterations borrowed frames need a row pitch of %d bytes (the width "
-                        "rounded up to 64), got %d", s->pitch[0], pitch_of(pl, 0, false));
-            for (int k = L - 1; k >= 0; --k) {
-                const ofx_geom g = level_geom(s, k, 0, s->h[k]);
-                const uint8_t *next_k = plane_of(pl, k);
-                const uint8_t *src = next_k;
-                if (k != L - 1) {
-                    sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], g, uvslot(pl) + 2 * k};
-                    src = s->itsh[b][0][k];
+        const int reach = s->p.window / 2 + 1;
+        auto clip = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+        for (int it = 1; it < s->p.iters; ++it) { // it = iterations done so far; this pass computes iteration it + 1
+            int ns = 0, nw = 0;
+            for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) {
+                if (pl < 1 || pl > last_frame) continue;
+                const int b = (int)(pl % B);
+                // (a borrowed level 0 is read in place here too; the launches below address a level's planes -- the caller's
+                // frame, the shifted and the warped image -- with ONE pitch, so borrowed frames must have the session's)
+                OFX_REQUIRE(!s->p.borrow_frames || (pitch_of(pl, 0, false) == s->pitch[0] && pitch_of(pl - 1, 0, false) == s->pitch[0]),
+                            "ofx_session_stream_submit: with refinement iterations borrowed frames need a row pitch of %d bytes (the "
+                            "width rounded up to 64), got %d", s->pitch[0], pitch_of(pl, 0, false));
+                for (int k = L - 1; k >= 0; --k) {
+                    // rows of this iteration on a shard: the own rows + (radius + 1) * (iters - 1 - it) either side, so that the
+                    // next warp finds the flow of every row its LK touches (whole levels: everything)
+                    const int ext = s->p.sharded ? reach * (s->p.iters - 1 - it) : 0;
+                    const int a = clip(s->own0[k] - ext, 0, s->h[k]), e = clip(s->own1[k] + ext, 0, s->h[k]);
+                    const int wa = clip(a - reach, s->buf0[k], s->buf1[k]), we = clip(e + reach, s->buf0[k], s->buf1[k]);
+                    const uint8_t *next_k = plane_of(pl, k);
+                    const uint8_t *src = next_k;
+                    if (k != L - 1) {
+                        // the globally shifted next image, every row the buffers hold (once per pair, before iteration 2)
+                        if (it == 1) sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], level_geom(s, k, s->buf0[k], s->buf1[k]), uvslot(pl) + 2 * k};
+                        src = s->itsh[b][0][k];
+                    }
+                    wd[nw] = ofx_warp_desc{src, s->itsh[b][1][k], level_geom(s, k, wa, we), s->flowset[b][k], s->fl0[k], OFX_ITER_SCALE,
+                                           s->p.sharded ? s->corner_status : nullptr, 16 + k};
+                    ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][1][k], level_geom(s, k, a, e), s->flowset[b][k], s->fl0[k], nullptr, 1, s->p.min_det};
+                    ++nw;
                 }
-                wd[nw] = ofx_warp_desc{src, s->itsh[b][1][k], g, s->flowset[b][k], 0, OFX_ITER_SCALE};
-                ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][1][k], g, s->flowset[b][k], 0, nullptr, 1, s->p.min_det};
-                ++nw;
             }
-        }
-        if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
-        for (int it = 1; it < s->p.iters; ++it) {
+            if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
             OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nw, stream); }));
             OFX_TRY(timed_launch(s, OFX_TIME_LK_ACC, stream, [&] { return ofx_lk_levels(ld, nw, s->p.window, s->p.mode, stream); }));
         }
@@ -870,7 +899,6 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
                 "ofx_session_stream_begin: on a sharded session the stream pipeline needs local_corner (the corner flows "
                 "computed from each frame's top-left patch); otherwise drive the staged API");
     OFX_REQUIRE(s->p.levels >= 2 && s->p.levels - 1 <= 6, "ofx_session_stream_begin: %d levels unsupported (2..7)", s->p.levels);
-    OFX_REQUIRE(s->p.iters <= 1 || !s->p.sharded, "ofx_session_stream_begin: refinement iterations need an unsharded session");
     // staging work of the pair-at-a-time pipelined path may still be in flight on the session's own stream; the stream
     // pipeline is about to reuse the same image sets from the caller's stream
     if (s->aux) OFX_HIP(hipStreamSynchronize(s->aux));
@@ -958,7 +986,7 @@ extern "C" int ofx_session_flow_of(ofx_session *s, int pair, int level, float **
     const int B = stream_batch_of(s);
     OFX_REQUIRE(pair >= 1 && pair <= s->reported && pair > s->reported - B,
                 "ofx_session_flow_of: pair %d is not among the newest %d completed pairs (newest: %ld)", pair, B, s->reported);
-    if (d_ptr) *d_ptr = s->flowset[pair % B][level];
+    if (d_ptr) *d_ptr = s->flowset[pair % B][level] + s->flow_own_offset(level);
     if (row0) *row0 = s->own0[level];
     if (rows) *rows = s->own1[level] - s->own0[level];
     return OFX_OK;

@@ -362,6 +362,9 @@ struct WarpArgs {
     const float *flow; // interleaved (u,v), row (y - flow_row0)
     float scale;
     int w, h, pitch, row0, out_y0, out_y1, flow_row0, blocks_x;
+    int row_end;  // the planes hold image rows [row0, row_end)
+    int *status;  // optional: bit status_bit is set when a source row inside the image lay outside the planes
+    int status_bit;
 };
 
 struct WarpTable {
@@ -427,13 +430,25 @@ __device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
             ymax = max(ymax, y1[k]);
         }
     }
+    if (A.row0 > 0 || A.row_end < A.h) { // wave-uniform: a row window of the level (row-sharded caller)
+        bool miss = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < npx && (yi[k] < A.row0 || y1[k] >= A.row_end)) miss = true;
+            yi[k] = min(max(yi[k], A.row0), A.row_end - 1);
+            y1[k] = min(max(y1[k], A.row0), A.row_end - 1);
+        }
+        ymin = min(max(ymin, A.row0), A.row_end - 1);
+        ymax = min(max(ymax, A.row0), A.row_end - 1);
+        if (miss && finite && A.status != nullptr) atomicOr(A.status, 1 << A.status_bit);
+    }
     uint32_t out = 0;
     const int xbase = min(xmin, A.pitch - 8); // the 8-byte window stays inside the row pitch
     if (npx > 0 && finite && A.pitch >= 8 && xmax - xbase <= 7 && ymax - ymin <= 2) {
         uint32_t lo[3], hi[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int yr = min(ymin + r, A.h - 1); // rows past ymax are never selected
+            const int yr = min(ymin + r, min(A.h, A.row_end) - 1); // rows past ymax are never selected
             const uint8_t *row = A.src + (size_t)(yr - A.row0) * (size_t)A.pitch + xbase;
             __builtin_memcpy(&lo[r], row, 4);
             __builtin_memcpy(&hi[r], row + 4, 4);

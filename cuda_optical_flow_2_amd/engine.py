@@ -370,14 +370,15 @@ def warp_u8(src1: np.ndarray, flow: np.ndarray, scale: float) -> np.ndarray:
     from .lib import Geom
 
     class WarpDesc(C.Structure):
-        _fields_ = [("d_src", _vp), ("d_dst", _vp), ("geom", Geom), ("d_flow", _vp), ("flow_row0", C.c_int), ("scale", C.c_float)]
+        _fields_ = [("d_src", _vp), ("d_dst", _vp), ("geom", Geom), ("d_flow", _vp), ("flow_row0", C.c_int), ("scale", C.c_float),
+                    ("d_status", _vp), ("status_bit", C.c_int)]
 
     L = _lib.load()
     h, w = src1.shape
     ts, pitch = _u8_plane(src1)
     td = torch.zeros_like(ts)
     tf = torch.from_numpy(np.ascontiguousarray(flow, dtype=np.float32)).cuda()
-    d = WarpDesc(ts.data_ptr(), td.data_ptr(), Geom.full(w, h, pitch), tf.data_ptr(), 0, scale)
+    d = WarpDesc(ts.data_ptr(), td.data_ptr(), Geom.full(w, h, pitch), tf.data_ptr(), 0, scale, None, 0)
     check(L.ofx_warp_levels(C.byref(d), 1, _stream_ptr()), "ofx_warp_levels")
     torch.cuda.synchronize()
     return td[:, :w].cpu().numpy()

@@ -46,6 +46,11 @@ class ShardPlan:
     world: int
     margin: int = 8  # rows of slack for the reference's global shift (|v| <= margin keeps the shift exact)
     halo_mode: str = "recompute"  # "recompute": halos rebuilt from a wider level-0 halo; "exchange": fetched from the neighbours
+    # refinement iterations (extension, ofx_params.iters): iteration j is computed on (radius + 1) * (iters - j) rows beyond the
+    # block, so that the warp of iteration j + 1 finds the flow of every row it needs without a neighbour; the warp itself may
+    # reach `warp_margin` rows further (|scale * v| + 1 <= warp_margin keeps it exact; the session reports when it did not)
+    iters: int = 1
+    warp_margin: int = 8
     own: List[Range] = field(default_factory=list)   # rows whose flow this rank computes
     need: List[Range] = field(default_factory=list)  # rows of the images LK + shift may touch
     comp: List[Range] = field(default_factory=list)  # rows this rank downsamples itself (levels >= 1)
@@ -64,6 +69,8 @@ class ShardPlan:
         c0 = self.rank * base + min(self.rank, extra)
         c1 = c0 + base + (1 if self.rank < extra else 0)
         halo = self.window // 2 + 1 + self.margin
+        if self.iters > 1:
+            halo += (self.iters - 1) * (self.window // 2 + 1) + self.warp_margin
         self.own = [(c0 << (L - 1 - k), c1 << (L - 1 - k)) for k in range(L)]
         self.need = [_clip(self.own[k][0] - halo, self.own[k][1] + halo, hs[k]) for k in range(L)]
         # recompute mode: walk down from the coarsest level; what level k+1 computes dictates what level k must hold
@@ -107,7 +114,7 @@ class HipBackend:
         self.plan = plan
         self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan,
                                       local_corner=local_corner, patch_size=patch_size, stream_batch=stream_batch,
-                                      borrow_frames=borrow_frames)
+                                      borrow_frames=borrow_frames, iters=plan.iters)
         self._views = {}
         # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
         self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
@@ -180,10 +187,11 @@ class ShardedFlow:
     """One frame pair per step(), row-sharded over the ranks of the default process group."""
 
     def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True,
-                 corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute", borrow_frames=False):
+                 corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute", borrow_frames=False, iters=1):
         assert corner in ("broadcast", "local")
         assert halo_mode == "recompute" or corner == "broadcast", "the exchange mode is pair-at-a-time (rank 0's corner + broadcast)"
-        self.plan = ShardPlan(width, height, levels, window, rank, world, margin, halo_mode)
+        assert iters <= 1 or corner == "local", "refinement iterations on a sharded pair run through the stream pipeline (corner='local')"
+        self.plan = ShardPlan(width, height, levels, window, rank, world, margin, halo_mode, iters=iters)
         self.rank, self.world, self.pipelined, self.corner = rank, world, pipelined, corner
         self.backend = backend if backend is not None else HipBackend(self.plan, mode, device, corner == "local", patch_size,
                                                                       stream_batch, borrow_frames)

@@ -218,7 +218,10 @@ int ofx_shift_levels(const ofx_shift_desc *levels, int n, void *stream);
 int ofx_shift_1ch(const uint8_t *d_src, uint8_t *d_dst, const ofx_geom *g, const float *d_uv, void *stream);
 
 /* Extension (the reference has no iterations): d_dst(x,y) = round_u8(bilinear(d_src, x + scale*u, y + scale*v))
- * with (u,v) = d_flow at (x,y), replicate border, non-finite flow = no warp; whole levels only.  One refinement
+ * with (u,v) = d_flow at (x,y), replicate border, non-finite flow = no warp.  The planes may hold a row window of the level
+ * (geom.row0 / rows; rows [out_y0, out_y1) are produced): a source row the warp needs that lies inside the image but outside
+ * the window is replaced by the nearest row held and, when d_status is not NULL, bit status_bit is OR-ed into *d_status (a
+ * row-sharded caller's flow reached beyond its halo).  One refinement
  * iteration of a level = this warp of the (shifted) next image by the flow so far, then ofx_lk_levels with
  * accumulate = 1.  scale = OFX_ITER_SCALE turns the reference's flow units into pixels (Sobel gain 8 / Dt_3x3 gain 15). */
 #define OFX_ITER_SCALE 0.533333361148834228515625f
@@ -229,6 +232,8 @@ typedef struct ofx_warp_desc {
     const float *d_flow;
     int flow_row0;
     float scale;
+    int *d_status;  /* may be NULL */
+    int status_bit;
 } ofx_warp_desc;
 int ofx_warp_levels(const ofx_warp_desc *levels, int n, void *stream);
 
@@ -342,9 +347,10 @@ typedef struct ofx_params {
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
-/* local_corner sessions: *h_status receives (and the session clears) the OR over all pairs so far of bit k = "level k's
- * shift left the patch" and bit 8 + k = "level k's vertical shift reached image rows beyond this shard's halo" (the margin
- * rows of the plan); 0 = every pair so far is exactly the unsharded result.  Synchronises `stream`. */
+/* Sharded sessions: *h_status receives (and the session clears) the OR over all pairs so far of bit k = "level k's shift left
+ * the top-left patch" (local_corner), bit 8 + k = "level k's vertical shift reached image rows beyond this shard's halo" (the
+ * margin rows of the plan) and bit 16 + k = "a refinement iteration's warp at level k reached beyond the halo" (iters > 1);
+ * 0 = every pair so far is exactly the unsharded result.  Synchronises `stream`. */
 int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream);
 int ofx_session_destroy(ofx_session *s);
 /* Load the NEXT frame's level 0 (1ch, tightly packed w bytes per row, full frame) from host / device memory. */

@@ -30,6 +30,17 @@ pmc plain lk_level_kernel 1 4k plain lk_float
 pmc compat stream_kernel 3 4k stream compat_cpu
 pmc iters5_lk lk_level_kernel 1 4k plain lk_float 5
 pmc iters5_warp warp_u8_kernel 1 4k plain lk_float 5
+# traffic per launch for bench.py's roofline.traffic (keys: kernel, or kernel_<mode>_iters<n> for the non-default legs)
+python - $O/summary/${TAG}_traffic_pmc.jsonl > $O/summary/traffic_latest.json <<'PY'
+import json, sys
+rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
+names = ["stream_kernel", "lk_level_kernel", "stream_kernel_compat_cpu_iters1", "lk_level_kernel_lk_float_iters5", "warp_u8_kernel_lk_float_iters5"]
+out = {"4k": {n: r.get("bytes") for n, r in zip(names, rows)},
+       "note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc in separate passes (tools/profile_round.sh, tools/pmc_parse.py); "
+               "lk_level_kernel_lk_float_iters5 is the mean over the writing launch and the four accumulating ones of a pair"}
+print(json.dumps(out, indent=1))
+PY
+cat $O/summary/traffic_latest.json
 # keep the merge small: drop the big traces
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +2M -delete
