@@ -1106,3 +1106,56 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg, 
             for f in padded:
                 bad.stream_submit(f)
         bad.close()
+
+
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 3, 2), (1280, 768, 4, 7, 4, 4, 1), (1920, 1088, 5, 5, 2, 8, 4)])
+def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
+    """iters > 1 on row-sharded sessions (stream pipeline, local corner flows, nothing passed between the ranks): iteration j
+    is computed on (radius + 1) * (iters - j) rows beyond a rank's block, so that the warp of iteration j + 1 finds the flow
+    of every row its LK stencils touch in the rank's own buffers (parallel.ShardPlan(iters=...) sizes the halo).  R logical
+    ranks on one device, put together == the unsharded pair-at-a-time path, bit for bit; status words stay 0."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, iters, R, B = cfg
+    nf = 2 * B + 2
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, 0.6 * i, seed=29)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, "lk_float", iters=iters)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R, iters=iters), local_corner=True, stream_batch=B,
+                         iters=iters) for r in range(R)]
+    got, seen = {}, 0
+    for s in ranks:
+        s.stream_begin()
+
+    def snap(done):
+        nonlocal seen
+        if done >= 1:
+            for p in range(max(seen + 1, done - B + 1), done + 1):
+                got[p] = [torch.cat([s.flow_of(p, k)[0] for s in ranks], dim=0).cpu().numpy() for k in range(L)]
+            seen = done
+    for f in frames:
+        snap([s.stream_submit(f) for s in ranks][0])
+    while True:
+        d = [s.stream_drain() for s in ranks][0]
+        if d == -2:
+            break
+        snap(d)
+    assert sorted(got) == list(range(1, nf))
+    for p in range(1, nf):
+        for k in range(L):
+            assert_same(got[p][k], want[p][k], f"{R} ranks, iters={iters}: pair {p} level {k}")
+    for s in ranks:
+        assert s.corner_status() == 0
+        s.close()
+    # a plan made without its iterations has too small a halo: the session says so instead of computing something else
+    from cuda_optical_flow_2_amd.lib import OfxError
+    with pytest.raises(OfxError):
+        eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, 1, R), local_corner=True, iters=iters)
