@@ -1108,16 +1108,19 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg, 
         bad.close()
 
 
-@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 3, 2), (1280, 768, 4, 7, 4, 4, 1), (1920, 1088, 5, 5, 2, 8, 4)])
+@pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 3, 2, 8), (1280, 768, 4, 7, 4, 4, 1, 8), (1920, 1088, 5, 5, 2, 8, 4, 48)])
 def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
     """iters > 1 on row-sharded sessions (stream pipeline, local corner flows, nothing passed between the ranks): iteration j
     is computed on (radius + 1) * (iters - j) rows beyond a rank's block, so that the warp of iteration j + 1 finds the flow
     of every row its LK stencils touch in the rank's own buffers (parallel.ShardPlan(iters=...) sizes the halo).  R logical
-    ranks on one device, put together == the unsharded pair-at-a-time path, bit for bit; status words stay 0."""
+    ranks on one device, put together == the unsharded pair-at-a-time path, bit for bit; status words stay 0.  The warp
+    follows the flow, so a rank also holds `warp_margin` rows of slack: a 5x5 window on this texture produces outliers of
+    several rows (third configuration: 48 rows of slack; with the default 8 the same run differs in a few pixels next to a
+    cut AND says so: bit 16 + level of the status word)."""
     import torch
     from cuda_optical_flow_2_amd.parallel import ShardPlan
 
-    w, h, L, win, iters, R, B = cfg
+    w, h, L, win, iters, R, B, wm = cfg
     nf = 2 * B + 2
     frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, 0.6 * i, seed=29)[1]).cuda() for i in range(nf)]
     plain = eng.Session(w, h, L, win, "lk_float", iters=iters)
@@ -1129,8 +1132,12 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
         want[i] = [plain.flow_host(k) for k in range(L)]
         plain.swap()
     plain.close()
-    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R, iters=iters), local_corner=True, stream_batch=B,
-                         iters=iters) for r in range(R)]
+    def run(warp_margin):
+        ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R, iters=iters, warp_margin=warp_margin),
+                             local_corner=True, stream_batch=B, iters=iters) for r in range(R)]
+        return ranks
+
+    ranks = run(wm)
     got, seen = {}, 0
     for s in ranks:
         s.stream_begin()
@@ -1155,6 +1162,19 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
     for s in ranks:
         assert s.corner_status() == 0
         s.close()
+    if wm > 8:   # the same with the default slack: whatever differs is flagged
+        ranks = run(8)
+        for s in ranks:
+            s.stream_begin()
+            for f in frames:
+                s.stream_submit(f)
+            while s.stream_drain() != -2:
+                pass
+        torch.cuda.synchronize()
+        st = [s.corner_status() for s in ranks]
+        for s in ranks:
+            s.close()
+        assert any(x >> 16 for x in st), [hex(x) for x in st]
     # a plan made without its iterations has too small a halo: the session says so instead of computing something else
     from cuda_optical_flow_2_amd.lib import OfxError
     with pytest.raises(OfxError):
