@@ -228,7 +228,8 @@ def test_config5_8k_eight_logical_ranks_and_streamed_iterations(eng, oracle):
     (1) the pair row-sharded over 8 logical ranks, every rank streaming its block with local corner flows (four frames per
         launch: 8 x 6 levels would exceed the 40 items of a launch), put together == the unsharded plain sequence;
     (2) its 10 refinement iterations through the stream pipeline == the pair-at-a-time path, every pair and level, bit for
-        bit (that path is tied to the oracle's orc_lk_iter_level at 1080p / 4K above and at small sizes with up to 5 levels
+        bit -- unsharded, and then ALL of config 5 at once: 8 logical ranks, each streaming its block with 10 iterations
+        (the ranks' blocks put together == the same unsharded result) (that path is tied to the oracle's orc_lk_iter_level at 1080p / 4K above and at small sizes with up to 5 levels
         in test_gpu_parity.py; the oracle needs minutes for an 8K pair with 10 iterations);
     (3) a 1/16-area crop of the same frames (1920x1088, the whole pipeline: 6 levels, 15x15, 10 iterations) against the
         oracle."""
@@ -261,7 +262,18 @@ def test_config5_8k_eight_logical_ranks_and_streamed_iterations(eng, oracle):
     for p in range(1, 4):
         for k in range(L):
             assert _same_bits(got[p][0][k], want[p][k]), f"8K iters={iters}: streamed pair {p} level {k} != pair-at-a-time"
-    del got, want, d_frames
+    del got
+    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R, iters=iters, warp_margin=16), local_corner=True,
+                         stream_batch=2, iters=iters) for r in range(R)]
+    got = _run_stream(eng, ranks, [v for v in d_frames[:4]], frames[:4], 2, L, w)
+    status = [s.corner_status() for s in ranks]
+    for s in ranks:
+        s.close()
+    assert status == [0] * R, [hex(x) for x in status]
+    for p in range(1, 4):
+        for k in range(L):
+            assert _same_bits(torch.cat([got[p][r][k] for r in range(R)], dim=0), want[p][k]), f"8K, 8 ranks, iters={iters}: pair {p} level {k}"
+    del got, want, d_frames, ranks
 
     cw, ch = 1920, 1088   # (even at every level that is downsampled; 1080 >> 3 = 135 is not)
     a, b = frames[0][:ch, :cw].copy(), frames[1][:ch, :cw].copy()

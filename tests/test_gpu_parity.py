@@ -1177,5 +1177,6 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
         assert any(x >> 16 for x in st), [hex(x) for x in st]
     # a plan made without its iterations has too small a halo: the session says so instead of computing something else
     from cuda_optical_flow_2_amd.lib import OfxError
-    with pytest.raises(OfxError):
-        eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, 1, R), local_corner=True, iters=iters)
+    if (win // 2 + 1) * iters > win // 2 + 1 + 8:   # (the default plan's margin of 8 rows does not cover the iterations' rows)
+        with pytest.raises(OfxError):
+            eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, 1, R), local_corner=True, iters=iters)
