@@ -257,8 +257,6 @@ def main():
 
     feed = None
     if not distributed:
-        if args.iters > 1:
-            args.path = "plain"
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
                               stream_batch=args.batch if args.path == "stream" else 1, borrow_frames=args.borrow and args.path == "stream")
         sess.push_frame_host(frames[0])
@@ -294,7 +292,7 @@ def main():
         if args.shard_halo == "exchange":
             args.shard_corner = "broadcast"
         driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner,
-                                      stream_batch=args.batch, halo_mode=args.shard_halo,
+                                      stream_batch=args.batch, halo_mode=args.shard_halo, iters=args.iters,
                                       borrow_frames=args.borrow and args.shard_corner == "local" and args.shard_halo != "exchange")
         sess = driver.session
         if args.shard_corner == "local":
@@ -527,6 +525,17 @@ def main():
         pairs_per_launch = args.batch if stream_like else 1   # a stream tick carries args.batch frames / pairs
         lk_bytes *= pairs_per_launch
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
+        iters_pair = None
+        if args.iters > 1:
+            # refinement iterations: the roofline is that of the whole pair -- every launch of the second pass event-timed
+            # and tagged (ofx_session_timing_read_kind); bytes per SURVEY 8d: 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid
+            pair_alg = ((LK_BYTES_PER_PX + (args.iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * own_px +
+                        PYR_BYTES_PER_DST_PX * sum(level_px(w, h, levels, own_rows)[1:]))
+            us_pair = sum(v[0] * v[2] for v in kinds.values() if v[2]) / roof_steps
+            iters_pair = {"algorithmic_bytes_per_pair": pair_alg, "kernel_us_per_pair": round(us_pair, 2),
+                          "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in kinds.items() if v[2]}}
+            lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, roof_steps
+            achieved = pair_alg / (us_pair * 1e-6) / 1e9 if us_pair else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -585,6 +594,10 @@ def main():
                 "traffic": traffic,
             },
         }
+        if iters_pair is not None:
+            out["roofline"].update(iters_pair)
+            out["roofline"]["kernel"] = (f"all launches of a pair with {args.iters} iterations (stream tick / LK, shift, {args.iters - 1} x warp, "
+                                         f"{args.iters - 1} x accumulating LK); avg_launch_us = kernel time per pair")
         if rccl_world is not None:
             out["rccl_world"] = rccl_world   # sum of ones over the communicator: the ranks RCCL actually connected
         if not stream_like:

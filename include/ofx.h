@@ -316,7 +316,10 @@ typedef struct ofx_params {
      * comp == own: halos come from the neighbours (exchange); comp == buf: halos are recomputed locally from a
      * wider halo one level below (no exchange).  Ignored (treated as own) when comp_y1[k] == 0. */
     int comp_y0[OFX_MAX_LEVELS], comp_y1[OFX_MAX_LEVELS];
-    /* refinement iterations per level (extension, lk_float only): 0 or 1 = the reference (no refinement) */
+    /* refinement iterations per level (extension, lk_float only): 0 or 1 = the reference (no refinement).  Unsharded
+     * sessions run them pair at a time (ofx_session_run_flow) or through the stream pipeline (one warp + one accumulating LK
+     * launch per iteration for all pairs of a tick); sharded sessions through the stream pipeline only (local_corner), with
+     * buf_y* holding own rows +- ((window/2 + 1) * iters + slack for the shift and the warp): parallel.ShardPlan(iters=...). */
     int iters;
     /* Sharded sessions: compute the corner flows (the reference's shift vectors, formed from pixel 0 of every coarser
      * flow level) LOCALLY from a small top-left patch of every frame instead of receiving them from the rank that owns

@@ -17,6 +17,7 @@ stats() { # name, bench args...
 stats stream
 stats plain --path plain
 stats iters5 --iters 5 --steps 200
+stats iters5_plain --iters 5 --steps 200 --path plain
 stats compat_cpu --mode compat_cpu
 pmc() { # name, kernel substring, skip, pmc_run args...
   n=$1; k=$2; skip=$3; shift 3
