@@ -37,6 +37,9 @@ struct LkTable {
 #ifndef OFX_LK_NT_STORES
 #define OFX_LK_NT_STORES 1
 #endif
+#ifndef OFX_LK_INTERIOR_VARIANT
+#define OFX_LK_INTERIOR_VARIANT 1
+#endif
 #ifndef OFX_LK_HBOX_SLIDE
 #define OFX_LK_HBOX_SLIDE 1
 #endif
@@ -619,8 +622,11 @@ typedef __attribute__((address_space(3))) uint8_t *lds_ptr;
 // kernel never has any, and the extra live registers would push it over its 96-VGPR budget)
 // FAST: the <= 1 ulp solve (lk_solve.h) instead of the replay of the reference's operation order
 // xlds: kLkWaveLds bytes of LDS private to this wave (the exchange in front of the flow stores, below)
-template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false>
-__device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, uint8_t *xlds)
+// INTERIOR: all 256 columns of the wave's tile lie inside the image (every tile of a row but its first and its last; the
+// dispatcher lk_wave below decides): the column masks are compile-time constants then -- no byte mask on the loaded rows, one
+// scalar multiplier pair for all four columns instead of four per-lane selects per step.
+template <int R, int MODE, bool SUMS, bool MAY_ACC, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
@@ -660,14 +666,16 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
     const int ye = min(ys + A.strip_h, A.out_y1);
 
     // column validity: bytes outside [0,w) read as zero, derivatives there are zero
-    const bool ld_ok = cb >= 0 && cb < A.w;
-    uint32_t bmask = 0;
-    int cm[4];
+    const bool ld_ok = INTERIOR || (cb >= 0 && cb < A.w);
+    uint32_t bmask = INTERIOR ? 0xffffffffu : 0u;
+    int cm[4] = {-1, -1, -1, -1};
+    if constexpr (!INTERIOR) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool in = (cb + j) >= 0 && (cb + j) < A.w;
-        cm[j] = in ? -1 : 0;
-        bmask |= in ? (0xffu << (8 * j)) : 0u;
+        for (int j = 0; j < 4; ++j) {
+            const bool in = (cb + j) >= 0 && (cb + j) < A.w;
+            cm[j] = in ? -1 : 0;
+            bmask |= in ? (0xffu << (8 * j)) : 0u;
+        }
     }
     uint32_t col_off = ld_ok ? (uint32_t)cb : 0u; // 32-bit lane offset on top of a wave-uniform row pointer
     uint32_t flow_off = 8u * (uint32_t)(cb > 0 ? cb : 0); // byte offset of this lane's first (u,v) pair in a flow row
@@ -699,7 +707,10 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
         }
         return v;
     };
-    auto finish_row = [&](uint32_t raw) -> uint32_t { return raw & bmask; };
+    auto finish_row = [&](uint32_t raw) -> uint32_t {
+        if constexpr (INTERIOR) return raw;
+        else return raw & bmask;
+    };
 
     // ---- fused shift ---------------------------------------------------------------------------------------------------
     // Below the top level the reference replaces next by cpu::shift_back_pyramid(next) (OptFlowCPU.cpp:241-282): pixel
@@ -849,7 +860,8 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
 
         // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
         // window only counts once its row has entered (yo >= y_first)
-        const uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
+        uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
+        if constexpr (INTERIOR) rowm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowm); // one scalar multiplier pair for all columns
         const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
         s2 ix[4], iy[4], it[4];
         derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
@@ -1037,5 +1049,26 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
 #undef OFX_LK_PRIO_STEP
 }
 
+
+// One wave of the fused level kernel: picks the variant for its tile (wave-uniform: two complete copies of the march, nothing
+// merges after them).
+template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false>
+__device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, uint8_t *xlds)
+{
+    if (wave >= T.first_block[T.n]) return;
+    int level = 0, hi = T.n;
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (wave >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
+    const int tile = (wave - T.first_block[level]) % T.lv[level].tiles_x;
+    const int cb0 = tile * TileGeom<R>::OUT_W - TileGeom<R>::LO_LANE * 4;
+#if OFX_LK_INTERIOR_VARIANT
+    if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_impl<R, MODE, SUMS, MAY_ACC, FAST, true>(T, wave, lane, xlds);
+    else
+#endif
+        lk_wave_impl<R, MODE, SUMS, MAY_ACC, FAST, false>(T, wave, lane, xlds);
+}
 
 } // namespace ofx_dev
