@@ -19,7 +19,9 @@ OUT = os.path.join(PKG, os.environ.get("OFX_BUILD_OUT", "libofx_hip.so"))  # exp
 OBJ = os.path.join(PKG, "csrc", "_obj" + os.environ.get("OFX_BUILD_TAG", ""))
 ARCH = "gfx950"
 
-SOURCES = ["lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp", "compat_gpu.cpp", "compat_cpu.cpp"]
+SOURCES = ["lk_inst_stream_f.hip", "lk_inst_stream_fast.hip", "lk_inst_stream_c.hip", "lk_inst_levels_f.hip", "lk_inst_levels_fast.hip",
+           "lk_inst_levels_c.hip", "lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp",
+           "compat_gpu.cpp", "compat_cpu.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
 # buys nothing on gfx950 (packed fp32 issues at half the rate of scalar fp32; tools/ubench/valu_rates.hip)
@@ -70,7 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return name
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if force or jobs or _stale(OUT, objs):
