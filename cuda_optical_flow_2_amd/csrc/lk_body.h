@@ -43,6 +43,9 @@ struct LkTable {
 #ifndef OFX_LK_HBOX_SLIDE
 #define OFX_LK_HBOX_SLIDE 1
 #endif
+#ifndef OFX_LK_FOLD_PRIMING
+#define OFX_LK_FOLD_PRIMING 1 // the strip's first R - 1 rows enter through the high halves (lk_wave_impl, "Priming, folded")
+#endif
 #ifndef OFX_LK_PROGRESS_PRIORITY
 #define OFX_LK_PROGRESS_PRIORITY 1
 #endif
@@ -299,126 +302,13 @@ struct TileGeom {
     static constexpr int OUT_W = (HI_LANE - LO_LANE + 1) * 4;
 };
 
-// ---- rows ---------------------------------------------------------------------------------------------------------
-// MI355X VALU cost model (tools/ubench/valu_rates.hip, profiles/r01_valu_rates.txt): v_add_u32 / v_and / fp32 add,
-// mul, fma issue in ~2 cycles per wave; integer multiply, bfe, DPP, SDWA, packed-16 and every fp64 op take ~4.
-// So the arithmetic below is done in fp32 on values that are small exact integers (|Ix|,|Iy| <= 1020,
-// |It| <= 3825, products < 2^22), and only the running sums are 32-bit integers.
-template <int MODE>
-struct Row; // one image row of this lane's 4 columns, unpacked
-template <>
-struct Row<OFX_MODE_LK_FLOAT> {
-    float p[4]; // prev
-    float d[4]; // next - prev   (It is linear: Dt (*) next - Dt (*) prev == Dt (*) (next - prev), OptFlowGpu.cu:1936-1940)
-};
-template <>
-struct Row<OFX_MODE_COMPAT_CPU> {
-    int p[4]; // prev
-    int n[4]; // next
-};
-
-__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_LK_FLOAT> &r)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.p[j] = (float)((praw >> (8 * j)) & 0xffu); // v_cvt_f32_ubyteN
-        r.d[j] = (float)((nraw >> (8 * j)) & 0xffu) - r.p[j];
-    }
-}
-
-__device__ __forceinline__ void unpack(uint32_t praw, uint32_t nraw, Row<OFX_MODE_COMPAT_CPU> &r)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.p[j] = (praw >> (8 * j)) & 0xff;
-        r.n[j] = (nraw >> (8 * j)) & 0xff;
-    }
-}
-
-__device__ __forceinline__ float lane_from_f(float x, bool left)
-{
-    const int xi = __float_as_int(x);
-    return __int_as_float(left ? lane_from<-1>(xi) : lane_from<1>(xi));
-}
-
-__device__ __forceinline__ float fmask(float x, int m) { return __int_as_float(__float_as_int(x) & m); }
-
-// Derivatives of the middle row of a 3-row window at this lane's 4 columns, as exact small integers held in floats.
-// cm[j] = all-ones when column j is inside the image.  Only Ix and Iy are masked: every product the window sums use
-// has Ix or Iy as a factor, so a zero (Ix,Iy) pair removes the pixel whatever It is.
-__device__ __forceinline__ void derivs(const Row<OFX_MODE_LK_FLOAT> &t, const Row<OFX_MODE_LK_FLOAT> &m,
-                                       const Row<OFX_MODE_LK_FLOAT> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
-                                       float (&it)[4])
-{
-    // separable Sobel pair (kernels.cpp:6-19): sm = [1 2 1]^T column sums, df = [-1 0 1]^T column differences;
-    // Dt_3x3 = [1 2 1]^T [1 2 1] - centre tap (kernels.cpp:20-24) applied to d = next - prev
-    float sm[6], df[6], g[6];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sm[j + 1] = __builtin_fmaf(2.0f, m.p[j], t.p[j]) + b.p[j];
-        df[j + 1] = b.p[j] - t.p[j];
-        g[j + 1] = __builtin_fmaf(2.0f, m.d[j], t.d[j]) + b.d[j];
-    }
-    sm[0] = lane_from_f(sm[4], true);
-    sm[5] = lane_from_f(sm[1], false);
-    df[0] = lane_from_f(df[4], true);
-    df[5] = lane_from_f(df[1], false);
-    g[0] = lane_from_f(g[4], true);
-    g[5] = lane_from_f(g[1], false);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ix[j] = fmask(sm[j + 2] - sm[j], cm[j]);
-        iy[j] = fmask(__builtin_fmaf(2.0f, df[j + 1], df[j]) + df[j + 2], cm[j]);
-        it[j] = __builtin_fmaf(2.0f, g[j + 1], g[j]) + g[j + 2] - m.d[j];
-    }
-}
-
-__device__ __forceinline__ void derivs(const Row<OFX_MODE_COMPAT_CPU> &t, const Row<OFX_MODE_COMPAT_CPU> &m,
-                                       const Row<OFX_MODE_COMPAT_CPU> &b, const int (&cm)[4], float (&ix)[4], float (&iy)[4],
-                                       float (&it)[4])
-{
-    // cpu path: int accumulator truncated after every tap (OptFlowCPU.cpp:102) => each Gaussian tap contributes
-    // floor(px * w): corner px>>4, edge px>>3, centre px>>2 (GAUS_KERNEL_3x3, kernels.cpp:61-64).
-    // side[] = a column's contribution when it is left/right of the centre, mid[] when it is the centre column;
-    // bits 0..15 hold prev, bits 16..31 next (both halves stay < 256: no carry between them).
-    int sm[6], df[6], side[6], mid[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        sm[j + 1] = t.p[j] + 2 * m.p[j] + b.p[j];
-        df[j + 1] = b.p[j] - t.p[j];
-        const int sp = (t.p[j] >> 4) + (m.p[j] >> 3) + (b.p[j] >> 4);
-        const int sn = (t.n[j] >> 4) + (m.n[j] >> 3) + (b.n[j] >> 4);
-        const int mp = (t.p[j] >> 3) + (m.p[j] >> 2) + (b.p[j] >> 3);
-        const int mn = (t.n[j] >> 3) + (m.n[j] >> 2) + (b.n[j] >> 3);
-        side[j + 1] = sp | (sn << 16);
-        mid[j] = mp | (mn << 16);
-    }
-    sm[0] = lane_from<-1>(sm[4]);
-    sm[5] = lane_from<1>(sm[1]);
-    df[0] = lane_from<-1>(df[4]);
-    df[5] = lane_from<1>(df[1]);
-    side[0] = lane_from<-1>(side[4]);
-    side[5] = lane_from<1>(side[1]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m8 = cm[j] & 0xff; // (unsigned char) wrap, OptFlowCPU.cpp:106
-        const int gsum = side[j] + mid[j] + side[j + 2];
-        ix[j] = (float)((sm[j + 2] - sm[j]) & m8);
-        iy[j] = (float)((df[j] + 2 * df[j + 1] + df[j + 2]) & m8);
-        it[j] = (float)(((gsum >> 16) - (gsum & 0xffff)) & 0xff); // It2 - It1 as unsigned char, OptFlowCPU.cpp:15,340
-    }
-}
-
 // ---- packed (in | out) form -------------------------------------------------------------------------------------------
 // The march keeps TWO derivative rows in flight: the one entering the vertical window and the one leaving it.  They go
 // through exactly the same arithmetic, on values that fit 16 bits (|Ix|,|Iy| <= 1020, |It| <= 4335 before the centre tap
 // is removed), so both are carried in ONE register per quantity: low half = entering row, high half = leaving row.
 // v_pk_*_i16 then does both rows per instruction, one DPP move carries both neighbours, and
 //     V += Ix_in*Iy_in - Ix_out*Iy_out      is ONE   v_dot2_i32_i16( (Ix_in,Ix_out), (Iy_in,-Iy_out), V ).
-// It also halves the row state in registers.  (OFX_LK_PACKED=0 keeps the earlier fp32 formulation for A/B runs.)
-#ifndef OFX_LK_PACKED
-#define OFX_LK_PACKED 1
-#endif
+// It also halves the row state in registers.
 typedef short s2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
@@ -566,40 +456,6 @@ __device__ __forceinline__ void accumulate_pk(const s2 (&ix)[4], const s2 (&iy)[
         vxy[j] = __builtin_amdgcn_sdot2(ix[j], ny, vxy[j], false);
         vxt[j] = __builtin_amdgcn_sdot2(nx, it[j], vxt[j], false);
         vyt[j] = __builtin_amdgcn_sdot2(ny, it[j], vyt[j], false);
-    }
-}
-
-// a*b as an exact int32 through the fp32 pipe: for integer-valued |a*b| < 2^22, fma(a, b, 1.5*2^23) has the product
-// in its low mantissa bits, so bits(fma) - bits(1.5*2^23) == a*b.  (fma f32: 2 cycles; v_mul_i32_i24: 4.)
-#define OFX_MAGIC 12582912.0f
-#define OFX_MAGIC_BITS 0x4B400000
-
-template <bool HAVE_OUT>
-__device__ __forceinline__ void accumulate(const float (&ix)[4], const float (&iy)[4], const float (&it)[4],
-                                           const float (&ox)[4], const float (&oy)[4], const float (&ot)[4], int (&vxx)[4],
-                                           int (&vyy)[4], int (&vxy)[4], int (&vxt)[4], int (&vyt)[4])
-{
-    // order of the planes: OptFlowCPU.cpp:347-358 / OptFlowGpu.cu:1948-1960
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int axx = __float_as_int(__builtin_fmaf(ix[j], ix[j], OFX_MAGIC));
-        const int ayy = __float_as_int(__builtin_fmaf(iy[j], iy[j], OFX_MAGIC));
-        const int axy = __float_as_int(__builtin_fmaf(ix[j], iy[j], OFX_MAGIC));
-        const int axt = __float_as_int(__builtin_fmaf(ix[j], it[j], OFX_MAGIC));
-        const int ayt = __float_as_int(__builtin_fmaf(iy[j], it[j], OFX_MAGIC));
-        int sxx = OFX_MAGIC_BITS, syy = OFX_MAGIC_BITS, sxy = OFX_MAGIC_BITS, sxt = OFX_MAGIC_BITS, syt = OFX_MAGIC_BITS;
-        if constexpr (HAVE_OUT) {
-            sxx = __float_as_int(__builtin_fmaf(ox[j], ox[j], OFX_MAGIC));
-            syy = __float_as_int(__builtin_fmaf(oy[j], oy[j], OFX_MAGIC));
-            sxy = __float_as_int(__builtin_fmaf(ox[j], oy[j], OFX_MAGIC));
-            sxt = __float_as_int(__builtin_fmaf(ox[j], ot[j], OFX_MAGIC));
-            syt = __float_as_int(__builtin_fmaf(oy[j], ot[j], OFX_MAGIC));
-        }
-        vxx[j] += axx - sxx;
-        vyy[j] += ayy - syy;
-        vxy[j] += axy - sxy;
-        vxt[j] += axt - sxt;
-        vyt[j] += ayt - syt;
     }
 }
 
@@ -808,41 +664,58 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
     // window, `out` around the row leaving it.  The leaving row's derivatives are recomputed from the image (its rows
     // are L2-resident: this wave read them NS steps ago) instead of being kept in an LDS ring: that costs one more
     // derivative stage per step but no LDS, no pack/unpack of 16-bit fields, and it lets occupancy follow VGPRs only.
-    // Row r of either window lives in slot (r - (y_first - 1)) mod 3, so the loop is unrolled three times and every
-    // slot index is a compile-time constant (no register-to-register rotation).
-    const int y_first = ys - R; // first derivative row this strip needs
-    const int nsteps = (ye - ys) + 2 * R;
-#if OFX_LK_PACKED
-    // Row r of both windows lives in slot (r - (y_first - 1)) mod 3 (the loop is unrolled three times so that every slot
-    // index is a compile-time constant); the high halves carry the stream of the leaving window, which is the same rows
-    // NS steps later: its rows before y_first - 1 are fed as zeros and its derivative rows before y_first are masked,
-    // so the strip's priming steps need no code of their own.
+    // Both windows share their registers (low halves: entering, high halves: leaving) and live in three slots, the rows
+    // (t, m, b) of step s in slots (s, s + 1, s + 2) mod 3: the loop is unrolled three times and every slot index is a
+    // compile-time constant (no register-to-register rotation).
+    //
+    // Priming, folded: the first output row ys needs the 2R + 1 derivative rows ys - R .. ys + R in the running sums and
+    // nothing leaves before output row ys + 1, so during the first steps the high halves have no leaving row to carry.  They
+    // carry ENTERING rows instead, with multiplier +1: the H = R - 1 rows ys - R .. ys - 2 ride in the high halves of steps
+    // 0 .. H - 1 while the low halves start at row ys - 1.  The high stream then jumps back to become the leaving window:
+    // its fetches of steps R - 1, R, R + 1 are rows ys - R - 1, ys - R, ys - R + 1 -- which is what `yo + 2` gives there, so
+    // the restart needs no code of its own -- its multiplier is 0 in steps H .. R + 1, and from step R + 2 on it is the row
+    // leaving.  The first row comes out at step PR = R + 1 instead of 2R: R - 1 steps less per strip (3 of 8 for the 9x9
+    // window, 8 of 18 for 19x19), which is 17 % -> 11 % of the steps of a 4K pair launched alone and what bounds the
+    // rows a rank of a sharded pair recomputes.  OFX_LK_FOLD_PRIMING=0 (H = 0) is the plain 2R-step priming.
+    constexpr int H = OFX_LK_FOLD_PRIMING ? R - 1 : 0;
+    constexpr int PR = 2 * R - H;    // steps before the first output row
+    const int y_first = ys - R;      // first derivative row this strip needs
+    const int y_lo0 = y_first + H;   // derivative row of the low halves at step 0
+    const int nsteps = (ye - ys) + PR;
     RowPk<MODE> wp[3];
     const s2 two = pk_two();
-    // rows of the leaving window before y_first - 1 are zeros
+    // rows of the leaving window before y_first - 1 are never used: fed as zeros
     auto fetch_out_prev = [&](int r) -> uint32_t { return r < y_first - 1 ? 0u : fetch_row(A.prev, r); };
     auto fetch_out_next = [&](int r) -> NextRaw { return r < y_first - 1 ? NextRaw{0u, 0u, 0u} : fetch_next(r); };
     refresh_map(y_first - 1);
-    unpack_pk(load_row(A.prev, y_first - 1), load_next(y_first - 1), 0u, 0u, wp[0]);
-    unpack_pk(load_row(A.prev, y_first), load_next(y_first), 0u, 0u, wp[1]);
-    unpack_pk(load_row(A.prev, y_first + 1), load_next(y_first + 1), finish_row(fetch_out_prev(y_first + 1 - NS)),
-              finish_next(fetch_out_next(y_first + 1 - NS)), wp[2]);
+    if constexpr (H > 0) {
+        unpack_pk(load_row(A.prev, y_lo0 - 1), load_next(y_lo0 - 1), load_row(A.prev, y_first - 1), load_next(y_first - 1), wp[0]);
+        unpack_pk(load_row(A.prev, y_lo0), load_next(y_lo0), load_row(A.prev, y_first), load_next(y_first), wp[1]);
+        unpack_pk(load_row(A.prev, y_lo0 + 1), load_next(y_lo0 + 1), load_row(A.prev, y_first + 1), load_next(y_first + 1), wp[2]);
+    } else {
+        unpack_pk(load_row(A.prev, y_lo0 - 1), load_next(y_lo0 - 1), 0u, 0u, wp[0]);
+        unpack_pk(load_row(A.prev, y_lo0), load_next(y_lo0), 0u, 0u, wp[1]);
+        unpack_pk(load_row(A.prev, y_lo0 + 1), load_next(y_lo0 + 1), 0u, 0u, wp[2]);
+    }
 
     int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
 
     auto body = [&](auto K, int s) {
         constexpr int k = decltype(K)::value; // s mod 3
-        const int yy = y_first + s;           // derivative row entering the window
-        const int yo = yy - NS;               // derivative row leaving it
+        const int yy = y_lo0 + s;             // derivative row entering the window (low halves)
+        const int yo = yy - NS;               // derivative row leaving it (high halves, once the folded priming is over)
+        const bool folded = H > 0 && s < H;   // high halves: the entering row y_first + s
+        const int yh = folded ? y_first + s : yo;
 
-        // Issue the loads of the rows the next step adds (yy + 2 and yo + 2).  They are finished (mask / permute / unpack)
-        // at the end of this step, before its flow stores: gfx9 counts loads and stores in one vmcnt and only orders
+        // Issue the loads of the rows the next step adds (yy + 2 and the high stream's).  They are finished (mask / permute /
+        // unpack) at the end of this step, before its flow stores: gfx9 counts loads and stores in one vmcnt and only orders
         // returns within a type, so a wait for a load that has younger stores outstanding is a wait for those stores too.
         if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
-        const uint32_t pf_ip = fetch_row(A.prev, yy + 2), pf_op = fetch_out_prev(yo + 2);
-        const NextRaw pf_in = fetch_next(yy + 2), pf_on = fetch_out_next(yo + 2);
+        const int ro = (H > 1 && s + 1 < H) ? y_first + s + 2 : yo + 2; // b row of the high stream's next step
+        const uint32_t pf_ip = fetch_row(A.prev, yy + 2), pf_op = fetch_out_prev(ro);
+        const NextRaw pf_in = fetch_next(yy + 2), pf_on = fetch_out_next(ro);
         // a refinement launch adds to the flow already there: its 8 floats are fetched with the rows and waited for once
-        const bool emit = s >= 2 * R;
+        const bool emit = s >= PR;
         const int y = yy - R;
         const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
         const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
@@ -858,9 +731,10 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
             }
         }
 
-        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the leaving
-        // window only counts once its row has entered (yo >= y_first)
-        uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yo >= y_first && yo >= 0 && yo < A.h) ? 0xffff0000u : 0u);
+        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182); the high halves
+        // count +1 while they carry an entering row, -1 once they carry the leaving one (yo >= y_first), 0 in between
+        const uint32_t him = folded ? 0x00010000u : (yo >= y_first ? 0xffff0000u : 0u);
+        uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yh >= 0 && yh < A.h) ? him : 0u);
         if constexpr (INTERIOR) rowm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowm); // one scalar multiplier pair for all columns
         const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
         s2 ix[4], iy[4], it[4];
@@ -875,71 +749,8 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
             pin_row(wp[k]);
         };
 
-#else
-    Row<MODE> win[3], wout[3];
-    {
-        refresh_map(y_first - 1);
-        const uint32_t p0 = load_row(A.prev, y_first - 1), n0 = load_next(y_first - 1);
-        const uint32_t p1 = load_row(A.prev, y_first), n1 = load_next(y_first);
-        unpack(p0, n0, win[0]);
-        unpack(p1, n1, win[1]);
-        wout[0] = win[0];
-        wout[1] = win[1];
-    }
-    uint32_t pf_ip = load_row(A.prev, y_first + 1), pf_in = load_next(y_first + 1);
-    uint32_t pf_op = pf_ip, pf_on = pf_in;
-
-    int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
-
-    auto body = [&](auto K, int s) {
-        constexpr int k = decltype(K)::value;               // s mod 3
-        constexpr int ko = ((k - NS % 3) % 3 + 3) % 3;      // (s - NS) mod 3
-        const int yy = y_first + s;                         // derivative row entering the window
-        const int yo = yy - NS;                             // derivative row leaving it
-        const bool have_out = s >= NS;
-
-        // take the prefetched rows, prefetch the next ones (consumed one step from now)
-        if (yy + 2 - map_base >= 64) refresh_map(have_out ? yo + 2 : yy + 2);
-        unpack(pf_ip, pf_in, win[(k + 2) % 3]);
-        pf_ip = load_row(A.prev, yy + 2);
-        pf_in = load_next(yy + 2);
-        if (have_out) {
-            unpack(pf_op, pf_on, wout[(ko + 2) % 3]);
-            pf_op = load_row(A.prev, yo + 2);
-            pf_on = load_next(yo + 2);
-        }
-
-        float ix[4], iy[4], it[4];
-        // rows outside the image have no derivatives (their window taps are skipped, OptFlowCPU.cpp:182)
-        const int rvi = (yy >= 0 && yy < A.h) ? -1 : 0;
-        const int cmi[4] = {cm[0] & rvi, cm[1] & rvi, cm[2] & rvi, cm[3] & rvi};
-        derivs(win[k], win[(k + 1) % 3], win[(k + 2) % 3], cmi, ix, iy, it);
-        if (have_out) {
-            float ox[4], oy[4], ot[4];
-            const int rvo = (yo >= 0 && yo < A.h) ? -1 : 0;
-            const int cmo[4] = {cm[0] & rvo, cm[1] & rvo, cm[2] & rvo, cm[3] & rvo};
-            derivs(wout[ko], wout[(ko + 1) % 3], wout[(ko + 2) % 3], cmo, ox, oy, ot);
-            accumulate<true>(ix, iy, it, ox, oy, ot, vxx, vyy, vxy, vxt, vyt);
-        } else {
-            accumulate<false>(ix, iy, it, ix, iy, it, vxx, vyy, vxy, vxt, vyt);
-        }
-        auto take_rows = [] {};
-
-#endif
         // ---- emit output row y = yy - R ------------------------------------------------------------------------
         // (one call site for take_rows, after the arithmetic and before the stores)
-#if !OFX_LK_PACKED
-        const bool emit = s >= 2 * R;
-        const int y = yy - R;
-        const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
-        const size_t rowpix = (size_t)(y - A.flow_row0) * (size_t)A.w; // scalar
-        float old_uv[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        if constexpr (!SUMS && MAY_ACC) {
-            if (A.accumulate && emit && out_lane)
-                for (int j = 0; j < 4; ++j)
-                    if (cb + j < A.w) old_uv[2 * j] = A.flow[2 * (rowpix + cb + j)], old_uv[2 * j + 1] = A.flow[2 * (rowpix + cb + j) + 1];
-        }
-#endif
         int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
         float uv[8];
         f32x4 xlo, xhi; // this lane's two chunks of the exchanged row (only defined, and only used, in emitting steps: the

@@ -69,6 +69,9 @@ using ofx_launch::g_stream_trace_blocks;
 using ofx_launch::g_trace_header;
 
 // lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu needs ~120: 4 blocks (<= 128)
+#ifndef OFX_PYR_PRIO
+#define OFX_PYR_PRIO 3 // priority of the marching-pyramid waves next to the LK waves (which go 3 -> 0 along their strips)
+#endif
 #ifndef OFX_STREAM_MIN_BLOCKS
 #define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 4)
 #endif
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(OFX_PYR_PRIO);
         pyr_march_wave(S.pyr[i], 4 * (b - S.first[i]) + wv, tid & 63);
     }
     if (S.trace && b < S.trace_blocks && (tid & 63) == 0) { // one record per wave: 4 per block
