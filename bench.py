@@ -152,7 +152,7 @@ def main():
     ap.add_argument("--copy-frames", action="store_true",
                     help="stream path: the session keeps its own copy of level 0 of every frame instead of reading the caller's ring "
                          "of frames in place (ofx_params.borrow_frames = 0); the default run reports this variant under extra")
-    ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8],
+    ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8, 16],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = "
                          "engine.suggest_stream_batch: by the working set of the pipeline (4K: 4 on one GPU, 8 per rank of a sharded pair)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
@@ -172,7 +172,7 @@ def main():
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
         args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow)
     while args.batch > 1 and (args.steps % args.batch or
-                              args.batch * WORKLOADS[args.workload][2] > 40):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
+                              args.batch * WORKLOADS[args.workload][2] > 80):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2
     # (the warm-up is rounded UP to whole ticks -- a few more untimed steps -- so that only K constrains the frames per launch)
     warmup_steps = (args.warmup + args.batch - 1) // args.batch * args.batch
@@ -654,7 +654,7 @@ def main():
             # the same configuration through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every
             # further iteration one warp + one accumulating LK launch over all levels of all B pairs (taller strips, 2 + 2 *
             # (iters - 1) launches per B pairs instead of 3 + 2 * iters per pair); frames read in place like the headline's
-            b9 = 4 if 4 * levels <= 40 else 2
+            b9 = 4 if 4 * levels <= 80 else 2
             s9 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it, stream_batch=b9, borrow_frames=args.borrow)
             s9.stream_begin()
             fd9 = StreamFeed(s9.stream_submit_frames, d_ring, b9)

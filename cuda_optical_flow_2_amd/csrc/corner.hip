@@ -18,7 +18,7 @@ __global__ __launch_bounds__(64) void corner_kernel(const CornerArgs A)
 {
     __shared__ float f0[2 * OFX_MAX_LEVELS];
     __shared__ __attribute__((aligned(16))) uint8_t cache[kCornerTileBytes + OFX_MAX_LEVELS * kCornerCacheBytes];
-    corner_wave<MODE, FAST>(A, (int)threadIdx.x, f0, cache);
+    corner_wave<MODE, FAST>(A.hd, A.lv, (int)threadIdx.x, f0, cache);
 }
 
 // Row-sharded sessions that RECEIVE their shift vectors (rank 0's corner kernel + broadcast) check them here: the level
@@ -65,13 +65,13 @@ int ofx_shard_margin_check(const float *d_uv, int levels, const int *heights, co
 }
 
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
-                    const int *shard_rows, CornerArgs *out)
+                    const int *shard_rows, CornerHead *out, CornerLevel *lv_out)
 {
     OFX_REQUIRE(levels && d_uv && n_levels >= 1 && n_levels <= OFX_MAX_LEVELS, "ofx_corner_flows: bad arguments");
     OFX_REQUIRE(window >= 3 && (window & 1), "ofx_corner_flows: window must be odd and >= 3 (got %d)", window);
     OFX_REQUIRE((window >> 1) <= kCornerMaxRadius, "ofx_corner_flows: window %d not supported (at most %d)", window, 2 * kCornerMaxRadius + 1);
     OFX_REQUIRE(mode == OFX_MODE_COMPAT_CPU || mode == OFX_MODE_LK_FLOAT || mode == OFX_MODE_LK_FLOAT_FAST, "ofx_corner_flows: bad mode %d", mode);
-    CornerArgs a{};
+    CornerHead a{};
     a.levels = n_levels;
     a.min_det = levels[0].min_det;
     a.radius = window >> 1;
@@ -89,7 +89,7 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
         const int col_end = cols && cols[k] > 0 ? cols[k] : g->w;
         OFX_REQUIRE(col_end <= g->pitch && col_end >= (a.radius + 2 < g->w ? a.radius + 2 : g->w),
                     "ofx_corner_flows: level %d holds %d columns, the corner needs %d", k, col_end, a.radius + 2);
-        a.lv[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0, col_end,
+        lv_out[k] = CornerLevel{levels[k].d_prev, levels[k].d_next, levels[k].d_flow, g->w, g->h, g->pitch, g->rows, levels[k].flow_row0, col_end,
                                 shard_rows ? shard_rows[4 * k] : 0, shard_rows ? shard_rows[4 * k + 1] : 0, shard_rows ? shard_rows[4 * k + 2] : 0,
                                 shard_rows ? shard_rows[4 * k + 3] : 0};
     }
@@ -100,7 +100,7 @@ int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mod
 extern "C" int ofx_corner_flows(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, void *stream)
 {
     CornerArgs a{};
-    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, nullptr, &a));
+    OFX_TRY(ofx_corner_args(levels, n_levels, window, mode, d_uv, nullptr, nullptr, nullptr, &a.hd, a.lv));
     if (mode == OFX_MODE_LK_FLOAT)
         hipLaunchKernelGGL((corner_kernel<OFX_MODE_LK_FLOAT, false>), dim3(1), dim3(64), 0, ofx_stream(stream), a);
     else if (mode == OFX_MODE_LK_FLOAT_FAST)

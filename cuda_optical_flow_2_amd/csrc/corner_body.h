@@ -17,13 +17,19 @@ struct CornerLevel {
     int need0, need1, valid0, valid1;
 };
 
-struct CornerArgs {
-    CornerLevel lv[OFX_MAX_LEVELS];
+// A corner chain: its header and, separately, its levels -- the stream kernel keeps the levels of all the chains of a tick in
+// one flat table ((pair, level) items, like the LK stage) so that sixteen chains fit its argument block.
+struct CornerHead {
     float *uv;   // 2 floats per level
     int *status; // optional: bit k is set when level k needed a pixel inside the image but outside its planes, bit 8 + k
                  // when level k's vertical shift sends the shard's reads to image rows its buffers do not hold
     int levels, radius;
     float min_det; // determinant guard of the solve (lk_solve.h), as the level kernel of the same pair applies it
+    int lv0;       // stream kernel: index of the chain's level 0 in the flat table
+};
+struct CornerArgs { // the stand-alone corner kernel
+    CornerHead hd;
+    CornerLevel lv[OFX_MAX_LEVELS];
 };
 
 // The chain's pixels come from LDS: before the walk, the wave copies the top-left corner of every level -- 16 x 16 bytes of
@@ -79,7 +85,7 @@ __device__ __forceinline__ int shifted_next(const CornerCache &C, const CornerLe
 
 // Copies the corners of every level into `cache` (levels * kCornerCacheBytes bytes of LDS private to this wave).  Rows
 // and dwords outside the planes are stored as zero (they are never selected: pix() tests the extents).
-__device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, uint8_t *cache)
+__device__ __forceinline__ void corner_prefetch(const CornerHead &A, const CornerLevel *lv, int lane, uint8_t *cache)
 {
     // Phase 1 issues every load of every level (branch-free: address clamped into the planes); phase 2, behind a
     // scheduling barrier, masks the values and stores them.  Without the split hipcc puts a wait behind each load.
@@ -88,7 +94,7 @@ __device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, u
     for (int k = 0; k < OFX_MAX_LEVELS; ++k) {
         pv[k] = nv[k][0] = nv[k][1] = nv[k][2] = nv[k][3] = 0u;
         if (k >= A.levels) continue; // uniform
-        const CornerLevel &L = A.lv[k];
+        const CornerLevel &L = lv[k];
         const int rows = min(L.h, L.row_end), last_c = L.pitch - 4;
         pv[k] = *reinterpret_cast<const uint32_t *>(L.prev + (size_t)min(lane >> 2, rows - 1) * (size_t)L.pitch + min((lane & 3) * 4, last_c));
 #pragma unroll
@@ -101,7 +107,7 @@ __device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, u
 #pragma unroll
     for (int k = 0; k < OFX_MAX_LEVELS; ++k) {
         if (k >= A.levels) continue;
-        const CornerLevel &L = A.lv[k];
+        const CornerLevel &L = lv[k];
         const int rows = min(L.h, L.row_end), last_c = L.pitch - 4;
         uint8_t *pc = cache + k * kCornerCacheBytes, *nc = pc + kCornerPrevDim * kCornerPrevDim;
         {
@@ -123,13 +129,13 @@ __device__ __forceinline__ void corner_prefetch(const CornerArgs &A, int lane, u
 // corners).  Only wave-level ordering is needed, so the
 // function can run inside a larger workgroup.
 template <int MODE, bool FAST = false>
-__device__ __forceinline__ void corner_wave(const CornerArgs &A, int lane, float *f0, uint8_t *cache)
+__device__ __forceinline__ void corner_wave(const CornerHead &A, const CornerLevel *lv, int lane, float *f0, uint8_t *cache)
 {
     uint8_t *tileP = cache, *tileQ = cache + kCornerPrevDim * kCornerPrevDim;
     cache += kCornerTileBytes;
-    corner_prefetch(A, lane, cache);
+    corner_prefetch(A, lv, lane, cache);
     for (int k = A.levels - 1; k >= 0; --k) {
-        const CornerLevel &L = A.lv[k];
+        const CornerLevel &L = lv[k];
         const CornerCache C{cache + k * kCornerCacheBytes, cache + k * kCornerCacheBytes + kCornerPrevDim * kCornerPrevDim};
         // shift vector: float accumulation, coarsest level first (OptFlowCPU.cpp:257-266)
         float u = 0.0f, v = 0.0f;

@@ -18,7 +18,8 @@ constexpr int kCornerScratch = 128;                  // LDS of a corner block: t
 struct StreamArgs {
     LkTable lk;
     PyrMarchArgs pyr[kPyrStages];
-    CornerArgs corner[OFX_STREAM_MAX_BATCH];
+    CornerHead corner[OFX_STREAM_MAX_BATCH];
+    CornerLevel corner_lv[OFX_MAX_LK_ITEMS]; // the chains' levels, flat: chain i's level k at [corner[i].lv0 + k]
     // blocks [0, OFX_STREAM_MAX_BATCH) = one corner wave each; [.., first[0]) LK (four waves per block);
     // [first[i], first[i+1]) pyramid stage i (four marching waves per block, pyr_march.h).
     // The LK blocks come first and are planned for a whole number of waves per SIMD (lk_wave_target): they all start at
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // the short latency-bound stages go first whenever they are ready to issue (the LK waves lower their own priority
         // from 3 to 0 as they advance, lk_body.h)
         __builtin_amdgcn_s_setprio(3);
-        if (b < S.n_corner && wv == 0) corner_wave<MODE, FAST>(S.corner[b], tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
+        if (b < S.n_corner && wv == 0) corner_wave<MODE, FAST>(S.corner[b], S.corner_lv + S.corner[b].lv0, tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
     } else if (b < S.first[0]) {
         lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLds);
     } else {

@@ -126,10 +126,14 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         }
         any += stage_blocks[2 * i] + stage_blocks[2 * i + 1];
     }
+    int n_clv = 0;
     for (int i = 0; i < g->n_corner; ++i) {
         const ofx_corner_stage &C = g->corner[i];
         OFX_REQUIRE(C.levels > 0, "ofx_stream_launch: empty corner stage");
-        OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &C.shard_rows[0][0], &S.corner[i]));
+        OFX_REQUIRE(n_clv + C.levels <= OFX_MAX_LK_ITEMS, "ofx_stream_launch: the corner stages have more than %d (pair, level) items", OFX_MAX_LK_ITEMS);
+        OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &C.shard_rows[0][0], &S.corner[i], S.corner_lv + n_clv));
+        S.corner[i].lv0 = n_clv;
+        n_clv += C.levels;
     }
     S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LK_ITEMS];

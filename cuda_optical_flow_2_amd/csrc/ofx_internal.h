@@ -49,7 +49,8 @@ namespace ofx_dev {
 struct PyrArgs;
 struct PyrMarchArgs;
 struct ShiftTable;
-struct CornerArgs;
+struct CornerHead;
+struct CornerLevel;
 } // namespace ofx_dev
 // row0/rows (NULL: whole levels): the global rows each destination plane (index 0 = the level-0 copy) holds
 int ofx_pyramid_args(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
@@ -60,10 +61,10 @@ int ofx_pyramid_march_args(const uint8_t *d_level0, int pitch0, int w, int h, ui
                            uint8_t *d_level0_copy, int copy_pitch, const int *row0, const int *rows, int target_waves,
                            ofx_dev::PyrMarchArgs *out, int *items);
 int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *out, int *blocks_out);
-// cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerArgs::status;
+// cols (NULL: full width): columns [0, cols[k]) each level's planes hold; d_status (NULL: none): see CornerHead::status;
 // shard_rows (NULL: unchecked): 4 ints per level, CornerLevel::need0 .. valid1
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
-                    const int *shard_rows, ofx_dev::CornerArgs *out);
+                    const int *shard_rows, ofx_dev::CornerHead *out, ofx_dev::CornerLevel *lv_out);
 // sharded sessions whose shift vectors come from another rank: raise status bit 8 + k when level k's vertical shift sends the
 // shard's reads (rows [need0, need1) before the shift) to image rows outside [valid0, valid1); shard_rows = 4 ints per level
 int ofx_shard_margin_check(const float *d_uv, int levels, const int *heights, const int *shard_rows, int *d_status, void *stream);

@@ -126,8 +126,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(p->min_det >= 0.0f, "ofx_session_create: min_det must be >= 0 (0 = the reference's unguarded solve)");
     OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
     OFX_REQUIRE(p->stream_batch == 0 || p->stream_batch == 1 || p->stream_batch == 2 || p->stream_batch == 4 ||
-                    p->stream_batch == 8,
-                "ofx_session_create: stream_batch %d (0, 1, 2, 4 or 8)", p->stream_batch);
+                    p->stream_batch == 8 || p->stream_batch == 16,
+                "ofx_session_create: stream_batch %d (0, 1, 2, 4, 8 or 16)", p->stream_batch);
     OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
                 p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
     OFX_REQUIRE(p->iters <= 1 || p->mode != OFX_MODE_COMPAT_CPU, "ofx_session_create: refinement iterations need mode lk_float");

@@ -50,7 +50,9 @@ extern "C" {
                                     pixel instead of 19.  Everything else (window sums, shift, pyramid) is bit-exact. */
 
 #define OFX_MAX_LEVELS 12
-#define OFX_MAX_LK_ITEMS 40 /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
+#ifndef OFX_MAX_LK_ITEMS /* (build experiments only: the shipped library and this header must agree) */
+#define OFX_MAX_LK_ITEMS 80
+#endif /* (level, pair) items one fused LK launch can carry (ofx_lk_levels, ofx_stream_launch) */
 
 const char *ofx_last_error(void);
 /* library/ABI version, bumped when a signature changes */
@@ -124,7 +126,9 @@ typedef struct ofx_shift_desc {
  * share one launch, which multiplies the strip height by B (1/B of the priming rows per output row) and divides the
  * number of launches by B.
  * ofx_session_stream_submit drives this; it is exposed for callers that manage their own buffers. */
-#define OFX_STREAM_MAX_BATCH 8
+#ifndef OFX_STREAM_MAX_BATCH
+#define OFX_STREAM_MAX_BATCH 16
+#endif
 typedef struct ofx_pyramid_stage {
     /* levels 1..levels-1 from d_frame, plus a copy of level 0 into d_levels[0] */
     const uint8_t *d_frame;
@@ -330,7 +334,7 @@ typedef struct ofx_params {
      * the patch; ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
-    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 / 8 = one launch per that many frames
+    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 / 8 / 16 = one launch per that many frames
      * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
     /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame

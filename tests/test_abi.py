@@ -21,7 +21,7 @@ def test_library_loads_and_reports_abi():
     from cuda_optical_flow_2_amd import lib
 
     L = lib.load()
-    assert L.ofx_abi_version() == 5
+    assert L.ofx_abi_version() == 6
     assert isinstance(L.ofx_last_error(), bytes)
 
 
@@ -190,7 +190,8 @@ def test_suggested_frames_per_launch():
     assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=True) == 4   # the measured optima
     assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=False) == 2
     assert suggest_stream_batch(1920, 1080, 4, None) == 8
+    assert suggest_stream_batch(1920, 1080, 4, None, borrow_frames=True) == 16
     assert suggest_stream_batch(7680, 4320, 6, None) == 2      # never below two frames per launch
     assert suggest_stream_batch(3840, 2160, 5, ShardPlan(3840, 2160, 5, 9, 3, 8), True) == 8
     for w, h, L in [(640, 480, 7), (7680, 4320, 6), (64, 64, 2)]:
-        assert suggest_stream_batch(w, h, L, None) * L <= 40   # OFX_MAX_LK_ITEMS
+        assert suggest_stream_batch(w, h, L, None) * L <= 80   # OFX_MAX_LK_ITEMS

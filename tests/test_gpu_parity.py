@@ -618,9 +618,10 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 
-@pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (1, True), (4, True), (8, True)])
+@pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (16, False), (1, True), (4, True), (8, True), (16, True)])
 @pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
-                                 (640, 480, 6, 9, "lk_float", 1, 14), (250, 186, 2, 7, "lk_float", 1, 7), (1280, 768, 7, 5, "lk_float", 2, 9)])
+                                 (640, 480, 6, 9, "lk_float", 1, 14), (250, 186, 2, 7, "lk_float", 1, 7), (1280, 768, 7, 5, "lk_float", 2, 9),
+                                 (320, 240, 3, 7, "lk_float", 2, 53)])  # the last: more than three full ticks of sixteen frames
 def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch, borrow):
     """ofx_params.stream_batch = B: one launch per B frames (the LK items of B pairs share a launch: taller strips, 1/B of
     the launches).  Only every B-th call launches; pairs complete B at a time and are read through ofx_session_flow_of.
@@ -633,7 +634,7 @@ def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch, borrow):
 
     w, h, L, win, mode, R, nf = cfg
     B = batch
-    if B * L > 40:
+    if B * L > 80:
         pytest.skip("stream_batch * levels exceeds OFX_MAX_LK_ITEMS")
     pitch = (w + 3) // 4 * 4 + 8
     def padded(a):

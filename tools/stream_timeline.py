@@ -24,7 +24,7 @@ Lib.ofx_debug_stream_trace(buf.data_ptr(), cap, None)
 for i in range(B):
     s.stream_submit(frames[(10 * B + i) % RING])
 torch.cuda.synchronize()
-MAXB = 8  # OFX_STREAM_MAX_BATCH: blocks [0, MAXB) are the corner blocks, 2 * MAXB pyramid stages
+MAXB = 16  # OFX_STREAM_MAX_BATCH: blocks [0, MAXB) are the corner blocks, 2 * MAXB pyramid stages
 first = (C.c_int * (2 * MAXB + 1))()
 Lib.ofx_debug_stream_trace(None, 0, first)
 first = list(first)
@@ -72,3 +72,34 @@ for k, e in zip(key[m].tolist(), ends.tolist()):
 for nw in sorted(set(cnt.values())):
     last = [max(v) for k, v in by.items() if len(v) == nw]
     print(f"  SIMDs with {nw} LK waves: {len(last)}, last LK end median {np.median(last):.1f} max {max(last):.1f} us")
+
+# ---- what makes a SIMD late?  (the launch ends with its slowest SIMD) --------------------------------------------------------
+def simd_key(sl_):
+    simd_ = (hw[sl_] >> 4) & 3; cu_ = (hw[sl_] >> 8) & 0xf; sh_ = (hw[sl_] >> 12) & 1; se_ = (hw[sl_] >> 13) & 7
+    return (((xcc[sl_] * 8 + se_) * 2 + sh_) * 16 + cu_) * 4 + simd_
+last_by = {k: max(v) for k, v in by.items()}
+lasts = np.array(list(last_by.values()))
+print("per-SIMD last LK end percentiles 5/25/50/75/95/100:", [round(float(np.percentile(lasts, q)), 1) for q in (5, 25, 50, 75, 95, 100)])
+psl = slice(4 * first[0], 4 * nb)
+pk = simd_key(psl)[ok[psl]]
+pyr_cnt = collections.Counter(pk.tolist())
+for n in sorted(set(pyr_cnt.values()) | {0}):
+    sel = [last_by[k] for k in last_by if pyr_cnt.get(k, 0) == n]
+    if sel:
+        print(f"  SIMDs hosting {n} pyramid wave(s): {len(sel)}, last LK end median {np.median(sel):.1f} p95 {np.percentile(sel, 95):.1f} max {max(sel):.1f}")
+kx = np.array(list(last_by.keys())) // (4 * 16 * 2 * 8)
+for x in range(8):
+    sel = lasts[kx == x]
+    if len(sel):
+        print(f"  XCD {x}: {len(sel)} SIMDs, last LK end median {np.median(sel):.1f} max {sel.max():.1f}")
+dur = (us[sl][:, 1] - us[sl][:, 0])
+nw_ = len(dur)
+print("LK wave duration by wave index (16 buckets, median):", [round(float(np.median(dur[i * nw_ // 16:(i + 1) * nw_ // 16][m[i * nw_ // 16:(i + 1) * nw_ // 16]])), 1) for i in range(16)])
+print("LK wave end by wave index (16 buckets, median / max):", [(round(float(np.median(us[sl][i * nw_ // 16:(i + 1) * nw_ // 16, 1])), 1), round(float(us[sl][i * nw_ // 16:(i + 1) * nw_ // 16, 1].max()), 1)) for i in range(16)])
+# the late SIMDs: the wave indices they host
+late = sorted(last_by, key=last_by.get)[-8:]
+widx = np.arange(nw_)
+allk = key
+for k in late:
+    ws = widx[(allk == k) & m]
+    print(f"  late SIMD {k}: last end {last_by[k]:.1f}, pyramid waves {pyr_cnt.get(k, 0)}, LK waves {[(int(i), round(float(dur[i]), 1), round(float(us[sl][i, 0]), 1)) for i in ws]}")
