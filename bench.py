@@ -258,7 +258,8 @@ def main():
     feed = None
     if not distributed:
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
-                              stream_batch=args.batch if args.path == "stream" else 1, borrow_frames=args.borrow and args.path == "stream")
+                              stream_batch=args.batch if args.path == "stream" else 1,
+                              borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)))
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
@@ -568,7 +569,8 @@ def main():
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
-                "frames": ("four resident device buffers, level 0 copied into the session per pair"
+                "frames": (("four resident device buffers, " + ("read in place (ofx_params.borrow_frames)" if driver is None and args.path == "plain"
+                                                                   and args.borrow and w % 64 == 0 else "level 0 copied into the session per pair"))
                            if not stream_like else f"a ring of {ring_n} distinct device buffers, " +
                            (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {3 * args.batch} further submits)"
                             if borrowed else "level 0 copied into the session")),

@@ -56,6 +56,7 @@ struct ofx_session {
     uint8_t *pimg[kSets][OFX_MAX_LEVELS]{};
     int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
     int *corner_status = nullptr;
+    const uint8_t *pframe[3] = {nullptr, nullptr, nullptr}; // borrow_frames, pair-at-a-time: the caller's frame behind img[i]'s level 0
     float *flow[OFX_MAX_LEVELS]{};       // where results are read from: flowset[0], or the newest pair's set in a two-frame stream
     float *flowset[kMaxBatch][OFX_MAX_LEVELS]{}; // stream pipeline: pair p's flow goes to set p mod stream_batch
     const uint8_t *held_frame[kMaxBatch]{};      // multi-frame stream tick: the frames waiting for the tick to fill
@@ -100,6 +101,10 @@ static void repoint(ofx_session *s)
         s->plane[1][k] = s->img[(s->cur + 1) % 3][k];
         s->plane[2][k] = s->sh[s->sht][k];
     }
+    // borrowed frames: level 0 is the caller's buffer (same pitch as the session's plane; only ever read)
+    const size_t skip = (size_t)s->buf0[0] * (size_t)s->pitch[0];
+    if (s->pframe[s->cur]) s->plane[0][0] = const_cast<uint8_t *>(s->pframe[s->cur]) + skip;
+    if (s->pframe[(s->cur + 1) % 3]) s->plane[1][0] = const_cast<uint8_t *>(s->pframe[(s->cur + 1) % 3]) + skip;
 }
 
 static ofx_geom level_geom(const ofx_session *s, int k, int out0, int out1)
@@ -298,6 +303,10 @@ extern "C" int ofx_session_destroy(ofx_session *s)
 static int load_level0(ofx_session *s, const uint8_t *src, bool src_is_host, int src_pitch, hipStream_t st)
 {
     const int rows = s->buf1[0] - s->buf0[0];
+    if (s->pframe[(s->cur + 1) % 3]) { // (a borrowing session that is handed a host frame, or staged: back to its own plane)
+        s->pframe[(s->cur + 1) % 3] = nullptr;
+        repoint(s);
+    }
     OFX_HIP(hipMemcpy2DAsync(s->plane[1][0], (size_t)s->pitch[0], src + (size_t)s->buf0[0] * (size_t)src_pitch, (size_t)src_pitch,
                              (size_t)s->w[0], (size_t)rows, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
     s->have_next = true;
@@ -314,6 +323,17 @@ extern "C" int ofx_session_set_frame_device(ofx_session *s, const uint8_t *d_gra
 {
     OFX_REQUIRE(s && d_gray1, "ofx_session_set_frame_device: null argument");
     OFX_REQUIRE(pitch >= s->w[0], "ofx_session_set_frame_device: pitch %d < width %d", pitch, s->w[0]);
+    if (s->p.borrow_frames) {
+        // no copy: the pyramid, corner and LK launches read the caller's buffer in place -- until the run_flow of the pair in
+        // which this frame is the PREVIOUS one has run (include/ofx.h, borrow_frames)
+        OFX_REQUIRE(pitch == s->pitch[0] && ((uintptr_t)d_gray1 & 3) == 0,
+                    "ofx_session_set_frame_device: a borrowed frame needs the session's level-0 pitch (%d bytes: the width rounded up to 64; "
+                    "got %d) and a 4-byte aligned address", s->pitch[0], pitch);
+        s->pframe[(s->cur + 1) % 3] = d_gray1;
+        repoint(s);
+            s->have_next = true;
+        return OFX_OK;
+    }
     return load_level0(s, d_gray1, false, pitch, ofx_stream(stream));
 }
 
@@ -322,6 +342,10 @@ extern "C" int ofx_session_set_frame_host_3ch(ofx_session *s, const uint8_t *h_i
     OFX_REQUIRE(s && h_img3, "ofx_session_set_frame_host_3ch: null argument");
     OFX_REQUIRE(!s->p.sharded, "ofx_session_set_frame_host_3ch: not available on a sharded session");
     hipStream_t st = ofx_stream(stream);
+    if (s->pframe[(s->cur + 1) % 3]) {
+        s->pframe[(s->cur + 1) % 3] = nullptr;
+        repoint(s);
+    }
     OFX_HIP(hipMemcpyAsync(s->staging, h_img3, (size_t)s->w[0] * (size_t)s->h[0] * 3, hipMemcpyHostToDevice, st));
     // the reference reads channel 0 only (OptFlowCPU.cpp:102, OptFlowGpu.cu:1079)
     OFX_TRY(ofx_extract_ch0(s->staging, s->plane[1][0], s->w[0], s->h[0], s->pitch[0], stream));

@@ -346,7 +346,13 @@ typedef struct ofx_params {
      * frame g into its buffer on the stream, right before submitting it, therefore needs a ring of at least 3B + 1
      * buffers; one that writes asynchronously needs as many more as it has launches in flight.
      * Saves 2 bytes per level-0 pixel of HBM traffic per frame and a third of the pipeline's cache working set
-     * (DESIGN.md section 4.3).  0 = copy (any buffer lifetime). */
+     * (DESIGN.md section 4.3).  0 = copy (any buffer lifetime).
+     * Pair-at-a-time path (ofx_session_set_frame_device + build_pyramid + run_flow + swap): the flag makes
+     * ofx_session_set_frame_device remember the buffer instead of copying it (no copy launch; the pyramid, corner and LK
+     * launches read it in place).  There the buffer of a frame is read until the run_flow of the pair in which it is the
+     * PREVIOUS frame has run, and its pitch must be the session's level-0 pitch (the width rounded up to 64 bytes,
+     * ofx_session_plane reports it) at a 4-byte aligned address; host frames (ofx_session_set_frame_host*) and the staged
+     * path still copy. */
     int borrow_frames;
     /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */
     float min_det;

@@ -243,6 +243,37 @@ def test_sharded_session_reports_a_shift_beyond_its_halo(eng):
     assert any((st >> 8) & 0b10 for st in status[1:]), [hex(st) for st in status]
 
 
+def test_pair_at_a_time_borrowed_frames(eng):
+    """ofx_params.borrow_frames on the pair-at-a-time path: ofx_session_set_frame_device only remembers the buffer, the
+    pyramid, corner and LK launches read level 0 in place (no copy launch).  Same bits as the copying session; a frame whose
+    pitch is not the session's is refused."""
+    import torch
+
+    w, h, L, win = 640, 480, 4, 9
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, 0.8 * i, seed=78)[1]).cuda() for i in range(5)]
+    a = eng.Session(w, h, L, win, "lk_float")
+    b = eng.Session(w, h, L, win, "lk_float", borrow_frames=True)
+    for s in (a, b):
+        s.set_frame_device(frames[0]); s.build_pyramid(); s.swap()
+    for i in range(1, 5):
+        for s in (a, b):
+            s.set_frame_device(frames[i]); s.build_pyramid(); s.run_flow()
+        torch.cuda.synchronize()
+        for k in range(L):
+            assert_same(b.flow_host(k), a.flow_host(k), f"pair {i} level {k}")
+        a.swap(); b.swap()
+    # a host frame on a borrowing session goes into the session's own plane again
+    b.set_frame_host(frames[0].cpu().numpy()); b.build_pyramid(); b.run_flow()
+    a.set_frame_device(frames[0]); a.build_pyramid(); a.run_flow()
+    torch.cuda.synchronize()
+    assert_same(b.flow_host(0), a.flow_host(0), "host frame after borrowed frames")
+    a.close(); b.close()
+    c = eng.Session(250, 186, 2, 7, "lk_float", borrow_frames=True)
+    with pytest.raises(RuntimeError, match="pitch"):
+        c.set_frame_device(torch.zeros((186, 250), dtype=torch.uint8, device="cuda"))
+    c.close()
+
+
 def test_stream_submit_frames_equals_single_submits(eng):
     """ofx_session_stream_submit_frames(n frames) == n calls of ofx_session_stream_submit: same pairs reported, same bits;
     group sizes that do and do not line up with the frames per launch."""
