@@ -718,7 +718,7 @@ def main():
             if args.path == "stream" and args.workload == "4k":
                 # the metric names 1080p pairs next to 4K ones (BASELINE.json): the same pipeline on the 1080p configuration
                 wl5 = WORKLOADS["1080p"]
-                b5 = engine.suggest_stream_batch(*wl5[:3])
+                b5 = engine.suggest_stream_batch(*wl5[:3], None, True)  # (the leg reads its frames in place)
                 f5 = make_ring([torch.from_numpy(synth.smooth_pair(wl5[0], wl5[1], 2.0 * i * mx, 1.0 * i * my)[1]).cuda() for i in range(nframes)],
                                ring_size(b5))
                 r5 = stream_leg(wl5, args.mode, b5, True, f5, args.steps)

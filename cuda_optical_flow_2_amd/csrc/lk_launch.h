@@ -151,9 +151,10 @@ int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
 }
 
 // Number of LK waves a launch is planned for.  Every LK wave runs for the whole launch, so what matters is how many of
-// them share a SIMD: measured on MI355X (4K, 9x9) 3 per SIMD is the optimum once the march no longer waits on its own
-// loads -- fewer leave issue slots empty, more shorten the strips (each strip pays 2R priming rows) -- and a count that
-// is not a whole number per SIMD makes the fuller SIMDs set the time.  `reserve` slots per SIMD are left to the other
+// them share a SIMD: fewer leave issue slots empty, more shorten the strips (each strip pays its priming rows), and a count
+// that is not a whole number per SIMD makes the fuller SIMDs set the time.  Measured on MI355X (one 4K pair, 9x9): with 2R
+// priming steps per strip 3 per SIMD was the optimum; with the folded priming (R + 1 steps, lk_body.h) it is 4 -- 48.9 /
+// 42.0 / 40.4 / 41.6 us at 2 / 3 / 4 / 5.  `reserve` slots per SIMD are left to the other
 // stages of the stream kernel.
 template <typename K>
 int lk_wave_target(K kernel, int threads, size_t lds, int reserve, int dflt_per_simd)
@@ -176,7 +177,7 @@ int lk_wave_target(K kernel, int threads, size_t lds, int reserve, int dflt_per_
 template <int R, int MODE, bool SUMS, bool FAST>
 int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS, FAST>, 64, 0, 0, 3);
+    static const int capacity = lk_wave_target(lk_level_kernel<R, MODE, SUMS, FAST>, 64, 0, 0, 4);
     LkTable t{};
     const int blocks = plan_table<R>(lv, n, capacity, &t);
     hipLaunchKernelGGL((lk_level_kernel<R, MODE, SUMS, FAST>), dim3((unsigned)blocks), dim3(64), 0, st, t);

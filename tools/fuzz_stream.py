@@ -18,14 +18,14 @@ def run(n_cfg: int, seed: int, verbose: bool = True) -> int:
       h = step * int(rng.integers(2, max(3, 900 // step)))
       mode = "lk_float" if rng.random() < 0.7 else "compat_cpu"
       win = int(rng.choice([3, 5, 7, 9, 11, 15, 19, 23]))
-      B = int(rng.choice([1, 2, 4, 8]))
-      if B * L > 40:
+      B = int(rng.choice([1, 2, 4, 8, 16]))
+      if B * L > 80:
           B = 2
       borrow = bool(rng.random() < 0.4)
       R = int(rng.choice([1, 1, 2, 3, 4]))
       if (h >> (L - 1)) < R:
           R = 1
-      nf = int(rng.integers(3, 12 if B < 8 else 30))
+      nf = int(rng.integers(3, 12 if B < 8 else (30 if B < 16 else 56)))
       pitch = (w + 3) // 4 * 4 + 4 * int(rng.integers(0, 3))
       def padded(a):
           buf = torch.full((h, pitch), 0x77, dtype=torch.uint8, device="cuda")
