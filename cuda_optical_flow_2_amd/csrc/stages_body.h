@@ -373,12 +373,91 @@ struct WarpTable {
     int n;
 };
 
+// The warp of 4 adjacent pixels whose 16 taps lie inside a window of 3 rows x 8 bytes, in ~200 instructions (the general
+// form below, which also serves row windows, ragged ends and non-finite flows, needs ~330; PMC: 332 -> 226 VALU
+// instructions per wave, kernel cycles -6.5 %).  Same arithmetic per pixel as the restatement; what is lean is
+// the bookkeeping: |flow| summed once for the finiteness test, clamps as v_med3, the fraction as v_fract (exact for the
+// clamped, non-negative coordinate), the window extents as min3 / max3, and the taps picked by byte permutes -- per pixel
+// one selector (xi - xbase, x1 - xbase) applied to the three window rows, the six bytes gathered into a register pair and
+// the two rows (yi, y1) picked by a second permute whose selector is 0x0202 * row.  Returns false (nothing written) when
+// the thread does not qualify.
+struct WarpLean { // a row of this thread between its two stages
+    float fx[4], fy[4];
+    uint32_t selx[4], sela[4], selb[4];
+    uint32_t lo[3], hi[3]; // the 3 x 8-byte window (loads in flight between the stages)
+};
+// stage 1: coordinates, window test, selectors; issues the six window loads.  false: the thread does not qualify.
+__device__ __forceinline__ bool warp4_lean_prepare(const WarpArgs &A, int x0, int y, const float (&fu)[4], const float (&fv)[4], WarpLean &M)
+{
+    // every |s*u|, |s*v| <= 0.54e8 when the sum of the magnitudes is <= 1e8 (NaN / Inf fail the test): all four pixels finite
+    const float mag = ((__builtin_fabsf(fu[0]) + __builtin_fabsf(fv[0])) + (__builtin_fabsf(fu[1]) + __builtin_fabsf(fv[1]))) +
+                      ((__builtin_fabsf(fu[2]) + __builtin_fabsf(fv[2])) + (__builtin_fabsf(fu[3]) + __builtin_fabsf(fv[3])));
+    if (!(mag <= 1e8f)) return false;
+    const float xf0 = (float)x0, yf = (float)y, wmaxf = (float)(A.w - 1), hmaxf = (float)(A.h - 1);
+    int xi[4], yi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sx = __builtin_amdgcn_fmed3f((xf0 + (float)k) + A.scale * fu[k], 0.0f, wmaxf);
+        const float sy = __builtin_amdgcn_fmed3f(yf + A.scale * fv[k], 0.0f, hmaxf);
+        xi[k] = (int)sx;
+        yi[k] = (int)sy;
+        M.fx[k] = __builtin_amdgcn_fractf(sx); // == sx - (float)xi: sx >= 0, the difference is exact
+        M.fy[k] = __builtin_amdgcn_fractf(sy);
+    }
+    const int xmin = min(min(xi[0], xi[1]), min(xi[2], xi[3])), ximax = max(max(xi[0], xi[1]), max(xi[2], xi[3]));
+    const int ymin = min(min(yi[0], yi[1]), min(yi[2], yi[3])), yimax = max(max(yi[0], yi[1]), max(yi[2], yi[3]));
+    const int wmax = A.w - 1, hmax = A.h - 1;
+    const int xbase = min(xmin, A.pitch - 8); // the 8-byte window stays inside the row pitch
+    if (A.pitch < 8 || min(ximax + 1, wmax) - xbase > 7 || min(yimax + 1, hmax) - ymin > 2) return false;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const uint8_t *row = A.src + (size_t)(uint32_t)(min(ymin + r, hmax) * A.pitch + xbase); // (rows past y1 are never selected)
+        __builtin_memcpy(&M.lo[r], row, 4);
+        __builtin_memcpy(&M.hi[r], row + 4, 4);
+    }
+    const int cx = (int)0x0c0c0000 - xbase, c1 = 1 - xbase, cw = wmax - xbase;
+    const int cy = (int)0x0c0c0100 - 0x0202 * ymin;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // bytes (xi - xbase, x1 - xbase) of a window row into bytes 0, 1 (selector bytes 0-3: lo, 4-7: hi, 0x0c: zero)
+        M.selx[k] = ((uint32_t)min(xi[k] + c1, cw) << 8) | (uint32_t)(xi[k] + cx);
+        // row r's pair will sit at bytes 2r, 2r + 1 of a register pair (stage 2)
+        M.sela[k] = (uint32_t)(0x0202 * yi[k] + cy);
+        M.selb[k] = (uint32_t)(0x0202 * min(yi[k] + 1, hmax) + cy);
+    }
+    return true;
+}
+// stage 2: the window has arrived
+__device__ __forceinline__ uint32_t warp4_lean_finish(const WarpLean &M)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t0 = __builtin_amdgcn_perm(M.hi[0], M.lo[0], M.selx[k]), t1 = __builtin_amdgcn_perm(M.hi[1], M.lo[1], M.selx[k]),
+                       t2 = __builtin_amdgcn_perm(M.hi[2], M.lo[2], M.selx[k]);
+        const uint32_t t01 = __builtin_amdgcn_perm(t1, t0, 0x05040100u); // row 0's pair in bytes 0-1, row 1's in bytes 2-3
+        const uint32_t pa = __builtin_amdgcn_perm(t2, t01, M.sela[k]), pb = __builtin_amdgcn_perm(t2, t01, M.selb[k]);
+        const float p00 = (float)(pa & 0xffu), p01 = (float)((pa >> 8) & 0xffu);
+        const float p10 = (float)(pb & 0xffu), p11 = (float)((pb >> 8) & 0xffu);
+        const float a = p00 + M.fx[k] * (p01 - p00);
+        const float b = p10 + M.fx[k] * (p11 - p10);
+        const float v = a + M.fy[k] * (b - a);
+        out |= ((uint32_t)(int)(v + 0.5f) & 0xffu) << (8 * k);
+    }
+    return out;
+}
+
 // Bilinear warp of 4 adjacent pixels per thread.  The arithmetic per pixel is the restatement's (clamp to the image,
 // a = p00 + fx*(p01-p00), b = p10 + fx*(p11-p10), v = a + fy*(b-a), round half up); what differs is how the four taps are
 // fetched.  Flow fields are smooth, so the taps of a thread's 4 pixels almost always lie inside a window of 3 rows x 8
 // bytes: the thread then loads that window with 6 (unaligned) dword loads that are contiguous across the lanes of a wave
 // and picks the taps with v_perm_b32, instead of gathering 16 single bytes (the gather form is TA-bound: 43 us for a 4K
 // pyramid).  A thread whose taps do not fit, or that has a non-finite flow, takes the gather path.
+__device__ __forceinline__ uint32_t warp4_general(const WarpArgs &A, int x0, int y, int npx, const float (&fu)[4], const float (&fv)[4]);
+
+// One thread = four adjacent pixels of one row; a block = 256 threads of one row.  (Rows per thread were tried both ways in
+// round 2 -- 2 / 4 rows one after the other: 35.1 / 37.4 us per 4K pyramid against 33.8; 2 ... 16 rows with the next row's
+// flow prefetched during the current one: 39.3 ... 51.6 us -- the kernel wants many short waves.)
 __device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
 {
     if (blk >= T.first_block[T.n]) return;
@@ -404,6 +483,17 @@ __device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
         for (int k = 0; k < 4; ++k)
             if (k < npx) fu[k] = frow[2 * (x0 + k)], fv[k] = frow[2 * (x0 + k) + 1];
     }
+    uint32_t out;
+    WarpLean M;
+    // the lean form of the common case: whole-level planes, four pixels, taps inside a 3 x 8 window
+    if (npx == 4 && A.row0 == 0 && A.row_end >= A.h && warp4_lean_prepare(A, x0, y, fu, fv, M)) out = warp4_lean_finish(M);
+    else out = warp4_general(A, x0, y, npx, fu, fv);
+    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+}
+
+// The general form of a thread's four pixels (row windows, ragged ends, non-finite flows, taps outside a 3 x 8 window).
+__device__ __forceinline__ uint32_t warp4_general(const WarpArgs &A, int x0, int y, int npx, const float (&fu)[4], const float (&fv)[4])
+{
     int xi[4], yi[4], x1[4], y1[4];
     float fx[4], fy[4];
     bool finite = true;
@@ -489,7 +579,7 @@ __device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
             out |= (val & 0xffu) << (8 * k);
         }
     }
-    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+    return out;
 }
 
 } // namespace ofx_dev
