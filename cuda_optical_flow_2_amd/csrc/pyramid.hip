@@ -336,7 +336,7 @@ int ofx_shift_table(const ofx_shift_desc *levels, int n, ShiftTable *out, int *b
         OFX_REQUIRE(levels[i].d_src != levels[i].d_dst, "ofx_shift_1ch: in-place shift is not supported");
         OFX_REQUIRE(g->out_y0 >= g->row0 && g->out_y1 <= g->row0 + g->rows, "ofx_shift_1ch: output rows outside the buffer");
         if (g->out_y1 <= g->out_y0) continue;
-        const int bx = ofx_div_up(g->pitch / 4, 256);
+        const int bx = ofx_div_up(ofx_div_up(g->pitch, 16), 256);
         t.lv[m] = ShiftArgs{levels[i].d_src, levels[i].d_dst, levels[i].d_uv, g->w, g->h, g->pitch, g->row0, g->row0 + g->rows,
                             g->out_y0, g->out_y1, bx};
         t.first_block[m] = blocks;

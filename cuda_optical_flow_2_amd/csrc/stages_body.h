@@ -299,7 +299,9 @@ struct ShiftTable { // (level, pair) items: up to the levels of every pair of a 
     int n;
 };
 
-// one 256-thread block of the multi-level shift
+// one 256-thread block of the multi-level shift: a thread moves 16 adjacent pixels of a row (four groups of four).  With
+// one group per thread the launch was bound by the rate at which waves can be started -- 43 k waves for a 4K pyramid's 11
+// Mpx, 15 us for 22 MB of traffic -- and not by anything the waves did.
 __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int tid)
 {
     if (blk >= T.first_block[T.n]) return;
@@ -308,9 +310,9 @@ __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int ti
     const ShiftArgs &A = T.lv[level];
     const int block = blk - T.first_block[level];
     const int bx = block % A.blocks_x, by = block / A.blocks_x;
-    const int x0 = 4 * (bx * 256 + tid);
+    const int xt = 16 * (bx * 256 + tid);
     const int y = A.out_y0 + by;
-    if (x0 >= A.pitch || y >= A.out_y1) return;
+    if (xt >= A.pitch || y >= A.out_y1) return;
     const float u = A.uv[0], v = A.uv[1];
     const float ty = (float)y + v;
     const bool yin = ty > -1.0f && ty < (float)A.h;
@@ -319,37 +321,51 @@ __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int ti
     const uint8_t *srow = A.src + (size_t)((yhave ? ny : A.row0) - A.row0) * (size_t)A.pitch;
     const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
     const long long third = (long long)A.w * (long long)A.h;
-    // target columns of this lane's 4 pixels (the column map does not depend on the row)
-    int nx[4];
-    bool xin[4];
+    uint32_t res[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float tx = (float)(x0 + k) + u;
-        xin[k] = (x0 + k) < A.w && tx > -1.0f && tx < (float)A.w;
-        nx[k] = xin[k] ? (int)tx : 0;
-    }
-    uint32_t out;
-    if (yin && yhave && xin[0] && xin[1] && xin[2] && xin[3] && nx[1] == nx[0] + 1 && nx[2] == nx[0] + 2 && nx[3] == nx[0] + 3) {
-        // common case: four consecutive in-image targets -> one (generally unaligned) dword instead of four byte
-        // gathers; byte gathers cost a full address cycle per lane and made this kernel TA-bound
-        __builtin_memcpy(&out, srow + nx[0], 4);
-    } else {
-        out = 0;
+    for (int g = 0; g < 4; ++g) {
+        const int x0 = xt + 4 * g;
+        if (x0 >= A.pitch) continue;
+        // target columns of this group's 4 pixels (the column map does not depend on the row)
+        int nx[4];
+        bool xin[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int x = x0 + k;
-            int val = 0;
-            if (x < A.w) {
-                if (yin && yhave && xin[k]) {
-                    val = srow[nx[k]];
-                } else {
-                    val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
-                }
-            }
-            out |= (uint32_t)val << (8 * k);
+            const float tx = (float)(x0 + k) + u;
+            xin[k] = (x0 + k) < A.w && tx > -1.0f && tx < (float)A.w;
+            nx[k] = xin[k] ? (int)tx : 0;
         }
+        uint32_t out;
+        if (yin && yhave && xin[0] && xin[1] && xin[2] && xin[3] && nx[1] == nx[0] + 1 && nx[2] == nx[0] + 2 && nx[3] == nx[0] + 3) {
+            // common case: four consecutive in-image targets -> one (generally unaligned) dword instead of four byte
+            // gathers; byte gathers cost a full address cycle per lane
+            __builtin_memcpy(&out, srow + nx[0], 4);
+        } else {
+            out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = x0 + k;
+                int val = 0;
+                if (x < A.w) {
+                    if (yin && yhave && xin[k]) {
+                        val = srow[nx[k]];
+                    } else {
+                        val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
+                    }
+                }
+                out |= (uint32_t)val << (8 * k);
+            }
+        }
+        res[g] = out;
     }
-    *reinterpret_cast<uint32_t *>(A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + x0) = out;
+    uint8_t *drow = A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + xt;
+    if (xt + 16 <= A.pitch && (A.pitch & 15) == 0 && ((uintptr_t)A.dst & 15) == 0) {
+        *reinterpret_cast<uint4 *>(drow) = make_uint4(res[0], res[1], res[2], res[3]);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            if (xt + 4 * g < A.pitch) *reinterpret_cast<uint32_t *>(drow + 4 * g) = res[g];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
