@@ -46,6 +46,9 @@ struct LkTable {
 #ifndef OFX_LK_FOLD_PRIMING
 #define OFX_LK_FOLD_PRIMING 1 // the strip's first R - 1 rows enter through the high halves (lk_wave_impl, "Priming, folded")
 #endif
+#ifndef OFX_LK_HBOX_SLIDE_MAX_R
+#define OFX_LK_HBOX_SLIDE_MAX_R 12 // (4: the sliding box sums only where the neighbour columns are one lane away)
+#endif
 #ifndef OFX_LK_PROGRESS_PRIORITY
 #define OFX_LK_PROGRESS_PRIORITY 1
 #endif
@@ -239,18 +242,21 @@ __device__ __forceinline__ int hbox_one(const int (&q)[4], const int (&s)[4])
     return hbox_left<R, I, 1>(s, hbox_right<R, I, 1>(q, own));
 }
 
-// the value of relative column C (any lane): C in 0..3 is this lane's a[C], C < 0 lies in the lane to the left, C > 3 to the right
-// x - (column C's value) and x + (column C's value) for |lane distance| <= 1, the DPP operand in the instruction's first
-// source (dst = dpp(src0) - src1 is v_sub_u32_dpp, the form hipcc folds correctly; the "rev" form is the one it gets wrong,
-// see lane_shift_right): a running value is kept negated every other step so that only that form occurs.
+// (column C's value) - y, C relative to this lane's first column: C in 0..3 is this lane's a[C], C < 0 lies in a lane to the
+// left, C > 3 in one to the right.  All lane steps but the last are fenced moves (lane_from); the last one is the DPP
+// operand of the subtraction, in the instruction's first source (dst = dpp(src0) - src1 is v_sub_u32_dpp, the form hipcc
+// folds correctly; the "rev" form is the one it gets wrong, see lane_shift_right): a running value is kept negated every
+// other step so that only that form occurs.
 template <int C>
-__device__ __forceinline__ int col_minus(const int (&a)[4], int y) // (column C) - y
+__device__ __forceinline__ int col_minus(const int (&a)[4], int y)
 {
     if constexpr (C >= 0 && C <= 3) {
         return a[C] - y;
     } else {
         constexpr int idx = ((C % 4) + 4) % 4;
-        int r = __builtin_amdgcn_update_dpp(0, a[idx], C > 3 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - y;
+        constexpr int dist = (C - idx) / 4; // lanes away: > 0 to the right
+        const int near = lane_from<(dist > 0 ? dist - 1 : dist + 1)>(a[idx]);
+        int r = __builtin_amdgcn_update_dpp(0, near, dist > 0 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - y;
         asm volatile("" : "+v"(r));
         return r;
     }
@@ -259,9 +265,9 @@ __device__ __forceinline__ int col_minus(const int (&a)[4], int y) // (column C)
 template <int R>
 __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
 {
-    if constexpr (OFX_LK_HBOX_SLIDE && R <= 4) {
-        // Windows of neighbouring columns differ by one column leaving and one entering, and for R <= 4 both lie in this lane
-        // or the one next to it: out[0] and out[3] in full, then out[1] = out[0] - a(-R) + a(R + 1) and
+    if constexpr (OFX_LK_HBOX_SLIDE && R <= OFX_LK_HBOX_SLIDE_MAX_R) {
+        // Windows of neighbouring columns differ by one column leaving and one entering (for R <= 4 both lie in this lane or the
+        // one next to it, for R <= 8 up to two lanes away, else three): out[0] and out[3] in full, then out[1] = out[0] - a(-R) + a(R + 1) and
         // out[2] = out[3] - a(R + 3) + a(2 - R), each difference two instructions -- n = a(leaving) - out; out' = a(entering) - n
         // -- two short dependent chains, 11-12 instructions per quantity instead of 13.
         int q[4], s[4];
