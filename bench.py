@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--copy-frames", action="store_true",
                     help="stream path: the session keeps its own copy of level 0 of every frame instead of reading the caller's ring "
                          "of frames in place (ofx_params.borrow_frames = 0); the default run reports this variant under extra")
+    ap.add_argument("--three-stage", action="store_true",
+                    help="stream path: the three-tick pipeline (pyramid | corner a tick later | LK two ticks later) instead of "
+                         "ofx_params.stream_two_stage, which an unsharded stream with borrowed frames uses by default")
     ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8, 16],
                     help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = "
                          "engine.suggest_stream_batch: by the working set of the pipeline (4K: 4 on one GPU, 8 per rank of a sharded pair)")
@@ -165,12 +168,16 @@ def main():
     # A stream tick carries `batch` frames and a step is one frame: the timed K steps must be whole ticks, or frames would be
     # counted that were only queued.  Use the largest batch that divides K.
     args.borrow = not args.copy_frames
+    # two ticks instead of three between a frame and its flow (the corner blocks build their own patch pyramids): a third less
+    # of everything the pipeline keeps in flight, which is what lets eight 4K frames per launch stay in the Infinity Cache
+    args.two_stage = (args.borrow and not args.three_stage and args.path == "stream" and args.gpus == 1 and args.iters <= 1
+                      and os.environ.get("OFX_BENCH_FORCE_DIST") != "1")
     if args.batch == 0:
         from cuda_optical_flow_2_amd.engine import suggest_stream_batch
         from cuda_optical_flow_2_amd.parallel import ShardPlan
         bw, bh, bl, bwin = WORKLOADS[args.workload]
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
-        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow)
+        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow, args.two_stage)
     while args.batch > 1 and (args.steps % args.batch or
                               args.batch * WORKLOADS[args.workload][2] > 80):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch //= 2
@@ -230,8 +237,9 @@ def main():
         """n DISTINCT device buffers whose contents repeat every len(src) buffers"""
         return [src[i % len(src)] if i < len(src) else src[i % len(src)].clone() for i in range(n)]
 
-    def ring_size(batch):
-        return (3 * max(batch, 4) + 4 + 3) // 4 * 4
+    def ring_size(batch, depth=None):
+        depth = depth or (2 if args.two_stage else 3)   # ticks a borrowed frame stays in use
+        return (depth * max(batch, 4) + 4 + 3) // 4 * 4
 
     # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
     # hand them over: long enough for ofx_params.borrow_frames (frame f's buffer is read until the launch of submit f + 3 * batch), and
@@ -259,7 +267,8 @@ def main():
     if not distributed:
         sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
                               stream_batch=args.batch if args.path == "stream" else 1,
-                              borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)))
+                              borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)),
+                              two_stage=args.two_stage)
         sess.push_frame_host(frames[0])
 
         if args.path == "stream":
@@ -423,6 +432,11 @@ def main():
             if st != 0:
                 raise SystemExit(f"bench.py self-check FAILED: rank {rank} status word {st:#x} (a shift left the patch / the shard's halo)")
             what += "; shard status word 0"
+        elif args.two_stage:
+            st = sess.corner_status()
+            if st != 0:
+                raise SystemExit(f"bench.py self-check FAILED: status word {st:#x} (a corner shift left the patch: ofx_params.stream_two_stage)")
+            what += "; status word 0 (every corner shift stayed inside its patch)"
         return what
 
     # (timing experiments with ablated kernels, OFX_BUILD_DEFS=-DOFX_X_*: their results are wrong by construction)
@@ -572,7 +586,7 @@ def main():
                 "frames": (("four resident device buffers, " + ("read in place (ofx_params.borrow_frames)" if driver is None and args.path == "plain"
                                                                    and args.borrow and w % 64 == 0 else "level 0 copied into the session per pair"))
                            if not stream_like else f"a ring of {ring_n} distinct device buffers, " +
-                           (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {3 * args.batch} further submits)"
+                           (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {(2 if args.two_stage else 3) * args.batch} further submits)"
                             if borrowed else "level 0 copied into the session")),
                 "sharding": "none" if driver is None else (
                     f"row blocks over {world} rank(s), halos recomputed from a wider level-0 halo; " +

@@ -3,6 +3,7 @@
 
 #include "lk_solve.h"
 #include "ofx_internal.h"
+#include "stages_body.h"
 
 namespace ofx_dev {
 
@@ -31,6 +32,41 @@ struct CornerArgs { // the stand-alone corner kernel
     CornerHead hd;
     CornerLevel lv[OFX_MAX_LEVELS];
 };
+
+// ---- patch pyramids built by the corner block itself (two-stage stream pipeline) --------------------------------------------
+// Levels 1 .. n of the top-left pw[0] x ph[0] corner of two frames (a pair's previous and next frame), each level from the
+// one below with the pyramid's own stencil (down4, stages_body.h): the pyramid of such a patch IS the top-left part of the
+// frame's pyramid (the stencil 2x-1 .. 2x+1 never reaches past column / row 2 * w_k - 1).  One block of 256 threads, a
+// barrier per level; the planes are global memory private to the block's chain (written and read by this block only:
+// the workgroup's L1 sees its own stores).  256 x 256 level-0 pixels: ~43 groups of four pixels per thread and frame.
+struct PatchBuild {
+    int n;                                   // produced levels (0: nothing to build)
+    int pw[OFX_MAX_LEVELS], ph[OFX_MAX_LEVELS], pitch[OFX_MAX_LEVELS]; // [0]: the patch of the frame itself (pitch: per slot)
+    int off[OFX_MAX_LEVELS];                 // byte offset of level k inside a frame's patch planes
+    int frame_stride;                        // bytes between the planes of the slot's two frames
+};
+struct PatchBuildSlot {
+    const uint8_t *src[2]; // the frames (level 0, whole rows from column 0)
+    int src_pitch[2];
+    uint8_t *base;         // this slot's planes: frame f's level k at base + f * frame_stride + off[k]
+};
+
+__device__ __forceinline__ void patch_build_block(const PatchBuild &P, const PatchBuildSlot &S, int tid)
+{
+    for (int k = 1; k <= P.n; ++k) {
+        const int groups = (P.pw[k] + 3) / 4; // (the pitch covers the last group: it is the width rounded up to 64)
+        const int per_frame = groups * P.ph[k];
+        for (int i = tid; i < 2 * per_frame; i += 256) {
+            const int f = i >= per_frame ? 1 : 0, j = i - f * per_frame;
+            const int y = j / groups, x0 = 4 * (j - y * groups);
+            const uint8_t *src = k == 1 ? S.src[f] : S.base + (size_t)f * (size_t)P.frame_stride + P.off[k - 1];
+            const int sp = k == 1 ? S.src_pitch[f] : P.pitch[k - 1];
+            const uint32_t v = down4(src, sp, 0, 0, P.ph[k - 1], P.pw[k - 1], P.pw[k], x0, y);
+            *reinterpret_cast<uint32_t *>(S.base + (size_t)f * (size_t)P.frame_stride + P.off[k] + (size_t)y * (size_t)P.pitch[k] + x0) = v;
+        }
+        __syncthreads();
+    }
+}
 
 // The chain's pixels come from LDS: before the walk, the wave copies the top-left corner of every level -- 16 x 16 bytes of
 // prev (the window and its 3x3 stencils reach column/row radius + 1 <= 13) and 32 x 32 bytes of next (the same plus

@@ -20,6 +20,9 @@ struct StreamArgs {
     PyrMarchArgs pyr[kPyrStages];
     CornerHead corner[OFX_STREAM_MAX_BATCH];
     CornerLevel corner_lv[OFX_MAX_LK_ITEMS]; // the chains' levels, flat: chain i's level k at [corner[i].lv0 + k]
+    // two-stage pipeline: the corner blocks build the patch pyramids their chains read (same geometry for every chain)
+    PatchBuild patch;
+    PatchBuildSlot patch_slot[OFX_STREAM_MAX_BATCH];
     // blocks [0, OFX_STREAM_MAX_BATCH) = one corner wave each; [.., first[0]) LK (four waves per block);
     // [first[i], first[i+1]) pyramid stage i (four marching waves per block, pyr_march.h).
     // The LK blocks come first and are planned for a whole number of waves per SIMD (lk_wave_target): they all start at
@@ -90,7 +93,10 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // the short latency-bound stages go first whenever they are ready to issue (the LK waves lower their own priority
         // from 3 to 0 as they advance, lk_body.h)
         __builtin_amdgcn_s_setprio(3);
-        if (b < S.n_corner && wv == 0) corner_wave<MODE, FAST>(S.corner[b], S.corner_lv + S.corner[b].lv0, tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
+        if (b < S.n_corner) {
+            if (S.patch.n > 0) patch_build_block(S.patch, S.patch_slot[b], tid); // (all 256 threads; ends with a barrier)
+            if (wv == 0) corner_wave<MODE, FAST>(S.corner[b], S.corner_lv + S.corner[b].lv0, tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
+        }
     } else if (b < S.first[0]) {
         lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLds);
     } else {

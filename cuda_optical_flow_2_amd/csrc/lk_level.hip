@@ -22,6 +22,8 @@
 // Border semantics follow the reference exactly: image taps outside the image contribute nothing
 // (OptFlowCPU.cpp:98, OptFlowGpu.cu:1066-1075) and window taps outside the image are skipped
 // (OptFlowCPU.cpp:182-191) -- i.e. the image and the derivative planes are zero-extended.
+#include <string.h>
+
 #include "lk_launch.h"
 
 
@@ -126,7 +128,7 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         }
         any += stage_blocks[2 * i] + stage_blocks[2 * i + 1];
     }
-    int n_clv = 0;
+    int n_clv = 0, n_build = 0;
     for (int i = 0; i < g->n_corner; ++i) {
         const ofx_corner_stage &C = g->corner[i];
         OFX_REQUIRE(C.levels > 0, "ofx_stream_launch: empty corner stage");
@@ -134,7 +136,36 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &C.shard_rows[0][0], &S.corner[i], S.corner_lv + n_clv));
         S.corner[i].lv0 = n_clv;
         n_clv += C.levels;
+        if (C.build_patch) {
+            // the chain's patch pyramids are built by its own block first: one geometry for all the chains of a launch
+            OFX_REQUIRE(C.levels >= 2 && C.patch_w > 0 && C.patch_h > 0 && C.d_patch_src[0] && C.d_patch_src[1] && C.d_patch[0][1] && C.d_patch[1][1],
+                        "ofx_stream_launch: corner stage %d: incomplete patch description", i);
+            PatchBuild pb{};
+            pb.n = C.levels - 1;
+            pb.frame_stride = (int)(C.d_patch[1][1] - C.d_patch[0][1]);
+            for (int k = 0; k < C.levels; ++k) {
+                pb.pw[k] = C.patch_w >> k;
+                pb.ph[k] = C.patch_h >> k;
+                pb.pitch[k] = k ? C.patch_pitch[k] : 0;
+                pb.off[k] = k ? (int)(C.d_patch[0][k] - C.d_patch[0][1]) : 0;
+                OFX_REQUIRE(pb.pw[k] > 0 && pb.ph[k] > 0, "ofx_stream_launch: the patch is too small for %d levels", C.levels);
+                if (k) {
+                    OFX_REQUIRE((C.patch_pitch[k] & 3) == 0 && C.patch_pitch[k] >= ((pb.pw[k] + 3) & ~3) && ((uintptr_t)C.d_patch[0][k] & 3) == 0 &&
+                                    C.d_patch[1][k] == C.d_patch[0][k] + pb.frame_stride,
+                                "ofx_stream_launch: corner stage %d: bad patch plane at level %d", i, k);
+                    OFX_REQUIRE(((C.patch_w >> (k - 1)) & 1) == 0 && ((C.patch_h >> (k - 1)) & 1) == 0, "ofx_stream_launch: the patch must have even dimensions below its top level");
+                }
+            }
+            for (int f = 0; f < 2; ++f)
+                OFX_REQUIRE((C.patch_src_pitch[f] & 3) == 0 && C.patch_src_pitch[f] >= C.patch_w && ((uintptr_t)C.d_patch_src[f] & 3) == 0,
+                            "ofx_stream_launch: corner stage %d: bad patch source", i);
+            if (S.patch.n == 0) S.patch = pb;
+            else OFX_REQUIRE(memcmp(&S.patch, &pb, sizeof pb) == 0, "ofx_stream_launch: the corner stages of a launch must share one patch geometry");
+            S.patch_slot[i] = PatchBuildSlot{{C.d_patch_src[0], C.d_patch_src[1]}, {C.patch_src_pitch[0], C.patch_src_pitch[1]}, C.d_patch[0][1]};
+            ++n_build;
+        }
     }
+    OFX_REQUIRE(n_build == 0 || n_build == g->n_corner, "ofx_stream_launch: either every corner stage builds its patch or none does");
     S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;

@@ -55,6 +55,8 @@ struct ofx_session {
     // local_corner: the top-left patch of every frame as a pyramid of its own (same 5 sets as img)
     uint8_t *pimg[kSets][OFX_MAX_LEVELS]{};
     int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
+    // stream_two_stage: the patch planes the corner block of slot i builds for its pair (frame 0: previous, 1: next)
+    uint8_t *pscr[kMaxBatch][2][OFX_MAX_LEVELS]{};
     int *corner_status = nullptr;
     const uint8_t *pframe[3] = {nullptr, nullptr, nullptr}; // borrow_frames, pair-at-a-time: the caller's frame behind img[i]'s level 0
     float *flow[OFX_MAX_LEVELS]{};       // where results are read from: flowset[0], or the newest pair's set in a two-frame stream
@@ -135,6 +137,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
                 "ofx_session_create: stream_batch %d (0, 1, 2, 4, 8 or 16)", p->stream_batch);
     OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
                 p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
+    OFX_REQUIRE(!p->stream_two_stage || p->borrow_frames, "ofx_session_create: stream_two_stage needs borrow_frames (the corner stage reads "
+                                                            "both frames of a pair in the tick in which the second one arrives)");
     OFX_REQUIRE(p->iters <= 1 || p->mode != OFX_MODE_COMPAT_CPU, "ofx_session_create: refinement iterations need mode lk_float");
     OFX_REQUIRE(p->iters <= 1 || !p->sharded || p->local_corner,
                 "ofx_session_create: refinement iterations on a sharded session run through the stream pipeline, which needs local_corner");
@@ -152,7 +156,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->p = *p;
     // image sets: the stream pipeline cycles through 3B + 2 of them (B = frames per tick; a session created without a
     // stream_batch may still stream one frame per tick), the pair-at-a-time paths rotate the first three
-    const int n_sets = 3 * (p->stream_batch >= 2 ? p->stream_batch : 1) + 2;
+    const int n_sets = (p->stream_two_stage ? 2 : 3) * (p->stream_batch >= 2 ? p->stream_batch : 1) + 2;
     s->n_sets = n_sets;
     size_t total = 0;
     // (streamed refinement iterations: two more scratch planes per pair of a tick)
@@ -212,7 +216,9 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         flow_stride.push_back(flow_bytes);
     }
     std::vector<size_t> off_patch[kSets];
-    if (p->local_corner) {
+    std::vector<size_t> off_pscr; // (per level; slot i, frame f at + (2 i + f) * pscr_frame)
+    size_t pscr_frame = 0;
+    if (p->local_corner || p->stream_two_stage) {
         const int step = 1 << (p->levels - 1);
         int side = p->patch_size > 0 ? p->patch_size : step * ((p->window >> 1) + 2 + 8);
         if (p->patch_size <= 0 && side < 256) side = 256;
@@ -223,10 +229,20 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->ph[k] = ph0 >> k;
             s->ppitch[k] = (int)align_up((size_t)s->pw[k], 64);
             const size_t bytes = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
+            if (p->stream_two_stage) { // no patch pyramids per image set: the corner blocks build what they read
+                off_pscr.push_back(pscr_frame);
+                if (k >= 1) pscr_frame += bytes;
+                continue;
+            }
             for (int t = 0; t < n_sets; ++t) {
                 off_patch[t].push_back(total);
                 total += bytes;
             }
+        }
+        const size_t off_pscr_base = total;
+        if (p->stream_two_stage) {
+            total += pscr_frame * 2 * (size_t)(p->stream_batch >= 2 ? p->stream_batch : 1);
+            for (size_t &o : off_pscr) o += off_pscr_base;
         }
         const int need = (p->window >> 1) + 2;
         const int lc = p->levels - 1;
@@ -268,9 +284,13 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->flowset[t][k] = reinterpret_cast<float *>(base + (t < p->stream_batch ? off_flow2[k] + (size_t)(t - 1) * flow_stride[k] : off_flow[k]));
         s->flow[k] = s->flowset[0][k];
     }
-    if (p->local_corner)
+    if (p->local_corner && !p->stream_two_stage)
         for (int k = 0; k < p->levels; ++k)
             for (int t = 0; t < n_sets; ++t) s->pimg[t][k] = base + off_patch[t][k];
+    if (p->stream_two_stage)
+        for (int i = 0; i < (p->stream_batch >= 2 ? p->stream_batch : 1); ++i)
+            for (int f = 0; f < 2; ++f)
+                for (int k = 1; k < p->levels; ++k) s->pscr[i][f][k] = base + off_pscr[k] + (size_t)(2 * i + f) * pscr_frame;
     s->corner_status = reinterpret_cast<int *>(base + off_status);
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = p->sharded ? nullptr : base + off_staging;
@@ -746,6 +766,8 @@ extern "C" int ofx_session_corner_status(ofx_session *s, int *h_status, void *st
 // Frame f (0-based) belongs to tick f / B (B = stream_batch: 1, 2 or 4).  Pair p is (frame p-1 -> frame p).  The tick
 // whose first frame is f0 runs, side by side in one grid,
 //     pyramid(frames f0 .. f0+B-1) | corner(pairs f0-B .. f0-1) | LK(pairs f0-2B .. f0-B-1, shift fused)
+// (with ofx_params.stream_two_stage: pyramid(f0 .. f0+B-1) | corner(pairs f0 .. f0+B-1, on patch pyramids the corner blocks
+// build themselves) | LK(pairs f0-B .. f0-1): 2B + 2 image sets, a pair done one tick earlier)
 // so every stage consumes what earlier ticks wrote and the ticks are ordered by the stream.  Frame f lives in image set
 // f mod (3B+2) and pair p's shift vectors in slot p mod 2B: a set is last read by LK(pair f+1), at the latest in the tick
 // that starts with frame f+2B+1, and rewritten by the tick that holds frame f+3B+2; a slot is read by LK(pair p) one tick
@@ -756,7 +778,10 @@ static int stream_batch_of(const ofx_session *s) { return s->p.stream_batch >= 2
 static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *pitches, int n_frames, void *stream, int *completed_pair)
 {
     const int B = stream_batch_of(s);
-    const int sets = 3 * B + 2, slots = 2 * B;
+    // D = ticks between a frame's arrival and the LK stage of the pair it completes: 2 (pyramid | corner | LK), or 1 with
+    // stream_two_stage (the corner stage runs in the frame's own tick, on patch pyramids it builds itself)
+    const int D = s->p.stream_two_stage ? 1 : 2;
+    const int sets = (D + 1) * B + 2, slots = 2 * B;
     const long f0 = s->stream_n; // index of the first frame of this tick
     const int L = s->p.levels;
     auto uvslot = [&](long pair) { return s->uv + (size_t)(pair % slots) * 2 * OFX_MAX_LEVELS; };
@@ -799,7 +824,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
             P.row0[k] = s->buf0[k];
             P.rows[k] = s->buf1[k] - s->buf0[k];
         }
-        if (s->p.local_corner) { // the same frame's top-left patch, as a pyramid of its own
+        if (s->p.local_corner && D == 2) { // the same frame's top-left patch, as a pyramid of its own
             P.patch_w = s->pw[0];
             P.patch_h = s->ph[0];
             P.patch_levels = L;
@@ -815,11 +840,36 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
             P.d_patch_levels[0] = nullptr;
         }
     }
-    for (long pc = f0 - B; pc <= f0 - 1; ++pc) { // corner(pair pc): both pyramids complete since the previous tick
+    for (long pc = f0 - (D - 1) * B; pc <= f0 - (D - 1) * B + B - 1; ++pc) { // corner(pair pc)
         if (pc < 1 || pc > last_frame) continue;
+        const int slot_i = g.n_corner;
         ofx_corner_stage &C = g.corner[g.n_corner++];
         C.levels = L;
         C.d_uv = uvslot(pc);
+        if (D == 1) {
+            // two stages: the pair's second frame arrived with this tick; the block builds the patch pyramids of both frames
+            // (levels >= 1) into its slot's planes and walks the chain on them (level 0: the frames themselves, borrowed)
+            C.build_patch = 1;
+            C.patch_w = s->pw[0];
+            C.patch_h = s->ph[0];
+            for (int f = 0; f < 2; ++f) {
+                C.d_patch_src[f] = s->bframe[set_of(pc - 1 + f)];
+                C.patch_src_pitch[f] = s->bpitch[set_of(pc - 1 + f)];
+            }
+            for (int k = 0; k < L; ++k) {
+                C.patch_pitch[k] = s->ppitch[k];
+                C.d_patch[0][k] = s->pscr[slot_i][0][k];
+                C.d_patch[1][k] = s->pscr[slot_i][1][k];
+                const uint8_t *pp = k ? s->pscr[slot_i][0][k] : C.d_patch_src[0], *pn = k ? s->pscr[slot_i][1][k] : C.d_patch_src[1];
+                ofx_geom pg{s->w[k], s->h[k], k ? s->ppitch[k] : C.patch_src_pitch[1], 0, s->ph[k], 0, s->ph[k]};
+                C.level[k] = ofx_lk_desc{pp, pn, pg, nullptr, 0, nullptr, 0, s->p.min_det};
+                C.cols[k] = s->pw[k];
+            }
+            C.d_status = s->corner_status;
+            if (s->p.sharded) shard_reach(s, C.shard_rows);
+            continue;
+        }
+        // (three stages: both pyramids are complete since the previous tick)
         for (int k = 0; k < L; ++k) {
             // (both frames of a pair come through the same API with the same pitch; a borrowed level 0 uses the caller's)
             if (s->p.local_corner) {
@@ -838,7 +888,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         }
     }
     long newest = -1;
-    for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
+    for (long pl = f0 - D * B; pl <= f0 - D * B + B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
         if (pl < 1 || pl > last_frame) continue;
         float *const *fl = s->flowset[pl % B];
         for (int k = L - 1; k >= 0; --k) {
@@ -880,7 +930,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         auto clip = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
         for (int it = 1; it < s->p.iters; ++it) { // it = iterations done so far; this pass computes iteration it + 1
             int ns = 0, nw = 0;
-            for (long pl = f0 - 2 * B; pl <= f0 - B - 1; ++pl) {
+            for (long pl = f0 - D * B; pl <= f0 - D * B + B - 1; ++pl) {
                 if (pl < 1 || pl > last_frame) continue;
                 const int b = (int)(pl % B);
                 // (a borrowed level 0 is read in place here too; the launches below address a level's planes -- the caller's

@@ -52,7 +52,7 @@ class FrameGroup:
         self.ptrs = (_vp * self.n)(*[t.data_ptr() for t in self.tensors])
 
 
-def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borrow_frames: bool = False) -> int:
+def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borrow_frames: bool = False, two_stage: bool = False) -> int:
     """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream on MI355X: the largest B in {16, 8, 4} the
     launch can carry (OFX_MAX_LK_ITEMS = 80 (pair, level) items) whose cyclic working set stays inside the 256 MB Infinity
     Cache, else 2.  The working set is what lives between a frame's arrival and its last use: the session's 3B+2 image sets (the
@@ -64,9 +64,10 @@ def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borro
     sharded pair 8 (sixteen measured no better there: tools/shard_sim.py)."""
     rows = [(height >> k) if shard is None else (shard.buf[k][1] - shard.buf[k][0]) for k in range(levels)]
     level_bytes = [(width >> k) * rows[k] for k in range(levels)]
+    depth = 2 if two_stage else 3   # ticks a frame stays in use (ofx_params.stream_two_stage)
     for b in ((16, 8, 4) if shard is None else (8, 4)):  # (a rank of a sharded pair gains nothing from sixteen: measured)
-        ring = (3 * max(b, 4) + 4 + 3) // 4 * 4
-        working_set = (3 * b + 2) * sum(level_bytes[1 if borrow_frames else 0:]) + ring * level_bytes[0]
+        ring = (depth * max(b, 4) + 4 + 3) // 4 * 4
+        working_set = (depth * b + 2) * sum(level_bytes[1 if borrow_frames else 0:]) + ring * level_bytes[0]
         if b * levels <= 80 and working_set <= 230e6:
             return b
     return 2
@@ -77,7 +78,7 @@ class Session:
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
                  shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False,
-                 min_det: float = 0.0):
+                 min_det: float = 0.0, two_stage: bool = False):
         self.L = _lib.load()
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
@@ -87,6 +88,7 @@ class Session:
         p.stream_batch = int(stream_batch)
         p.borrow_frames = int(bool(borrow_frames))
         p.min_det = float(min_det)
+        p.stream_two_stage = int(bool(two_stage))
         self.shard = shard
         if shard is not None:
             p.sharded = 1

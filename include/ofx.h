@@ -160,6 +160,17 @@ typedef struct ofx_corner_stage {
     int cols[OFX_MAX_LEVELS];
     int *d_status;
     int shard_rows[OFX_MAX_LEVELS][4];
+    /* build_patch != 0: the stage first builds the patch pyramids it reads -- levels 1 .. levels-1 of the top-left
+     * patch_w x patch_h corner of BOTH frames, from d_patch_src[0] (the pair's previous frame) and d_patch_src[1] (its next
+     * frame) into d_patch[0][k] / d_patch[1][k] (pitch patch_pitch[k]) -- and then walks the chain.  level[k] must
+     * describe exactly those planes for k >= 1 and the frames themselves for k = 0.  With it a pair's shift vectors need
+     * nothing but the two frames, i.e. they can be formed in the tick in which the pair's second frame arrives
+     * (ofx_params.stream_two_stage). */
+    int build_patch, patch_w, patch_h;
+    const uint8_t *d_patch_src[2];
+    int patch_src_pitch[2];
+    uint8_t *d_patch[2][OFX_MAX_LEVELS];
+    int patch_pitch[OFX_MAX_LEVELS];
 } ofx_corner_stage;
 typedef struct ofx_stream_stages {
     ofx_pyramid_stage pyr[OFX_STREAM_MAX_BATCH];
@@ -356,7 +367,16 @@ typedef struct ofx_params {
     int borrow_frames;
     /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */
     float min_det;
-    int reserved[2];
+    /* Stream pipeline in TWO stages instead of three: a tick runs pyramid(its frames) | corner(the pairs its frames complete)
+     * | LK(the pairs of the tick before), the corner stage building the two small patch pyramids it needs itself
+     * (ofx_corner_stage.build_patch) instead of waiting a tick for the pyramid stage.  A pair's flow is complete one tick
+     * earlier, the pipeline holds 2B + 2 image sets instead of 3B + 2 and a borrowed frame f is read until the launch
+     * enqueued by the submit of frame f + 2B (ring of >= 2B + 1 buffers) -- which is what lets eight 4K frames per launch
+     * stay inside the Infinity Cache.  Needs borrow_frames.  Like local_corner, the shift vectors are exact while the
+     * shifted corner stays inside the patch (256 level-0 pixels or patch_size); ofx_session_corner_status reports (bit k)
+     * the pairs for which it did not. */
+    int stream_two_stage;
+    int reserved[1];
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);

@@ -191,6 +191,8 @@ def test_suggested_frames_per_launch():
     assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=False) == 2
     assert suggest_stream_batch(1920, 1080, 4, None) == 8
     assert suggest_stream_batch(1920, 1080, 4, None, borrow_frames=True) == 16
+    assert suggest_stream_batch(3840, 2160, 5, None, borrow_frames=True, two_stage=True) == 8   # ofx_params.stream_two_stage: 216 MB
+    assert suggest_stream_batch(7680, 4320, 6, None, borrow_frames=True, two_stage=True) == 2
     assert suggest_stream_batch(7680, 4320, 6, None) == 2      # never below two frames per launch
     assert suggest_stream_batch(3840, 2160, 5, ShardPlan(3840, 2160, 5, 9, 3, 8), True) == 8
     for w, h, L in [(640, 480, 7), (7680, 4320, 6), (64, 64, 2)]:

@@ -59,8 +59,8 @@ def _ring(frames_host, w, h, ring_n, pad, fill):
 
 def _run_stream(eng, sessions, views, frames_host, B, L, w):
     """Feed len(frames_host) frames through the sessions' stream pipeline; frame i is written into ring slot i % ring
-    (in stream order, right before its submit -- a slot is reused 16 submits later, well past the 3 * B the borrow
-    contract asks for).  Returns {pair: [[level k of rank r]]}."""
+    (in stream order, right before its submit -- a slot is reused a ring's length of submits later, past the 3 * B (2 * B with
+    stream_two_stage) the borrow contract asks for).  Returns {pair: [[level k of rank r]]}."""
     import torch
 
     ring_n = len(views)
@@ -90,35 +90,39 @@ def _run_stream(eng, sessions, views, frames_host, B, L, w):
     return got
 
 
-# (width, height, levels, window, mode, frames per launch, frames)
+# (width, height, levels, window, mode, frames per launch, frames, ofx_params.stream_two_stage)
 BENCHED = [
-    pytest.param((3840, 2160, 5, 9, "lk_float", 4, 22), id="4k-lk_float-batch4-the-bench-default"),
-    pytest.param((1920, 1080, 4, 7, "lk_float", 8, 27), id="1080p-lk_float-batch8"),
-    pytest.param((3840, 2160, 5, 9, "compat_cpu", 4, 14), id="4k-compat_cpu-batch4"),
+    pytest.param((3840, 2160, 5, 9, "lk_float", 8, 37, True), id="4k-lk_float-batch8-two-stage-the-bench-default"),
+    pytest.param((3840, 2160, 5, 9, "lk_float", 4, 22, False), id="4k-lk_float-batch4-three-stage"),
+    pytest.param((1920, 1080, 4, 7, "lk_float", 16, 53, True), id="1080p-lk_float-batch16-two-stage"),
+    pytest.param((1920, 1080, 4, 7, "lk_float", 8, 27, False), id="1080p-lk_float-batch8"),
+    pytest.param((3840, 2160, 5, 9, "compat_cpu", 8, 21, True), id="4k-compat_cpu-batch8-two-stage"),
 ]
 
 
 @pytest.mark.parametrize("cfg", BENCHED)
 def test_benchmarked_stream_configuration_is_bit_exact(eng, oracle, cfg):
-    """bench.py's timed configuration (ofx_params.stream_batch, borrow_frames, a ring of 16 padded buffers that is reused
-    while the stream runs) against the plain sequence for every pair and every level, and against the oracle for the
-    first and the last pair."""
+    """bench.py's timed configurations (ofx_params.stream_batch, borrow_frames, stream_two_stage, a ring of padded buffers of
+    bench.py's size that is reused while the stream runs) against the plain sequence for every pair and every level, and
+    against the oracle for the first and the last pair."""
     import torch
 
-    w, h, L, win, mode, B, nf = cfg
+    w, h, L, win, mode, B, nf, two_stage = cfg
     frames = [synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1] for i in range(nf)]   # bench.py's frames: (2,1) px per frame
     d_frames = [torch.from_numpy(f).cuda() for f in frames]
     want = _plain_sequence(eng, d_frames, w, h, L, win, mode)
     del d_frames
-    ring_n = (3 * max(B, 4) + 4 + 3) // 4 * 4          # bench.py's ring: 16 buffers (28 with eight frames per launch)
+    ring_n = ((2 if two_stage else 3) * max(B, 4) + 4 + 3) // 4 * 4   # bench.py's ring: 20 buffers for eight frames per launch in two stages
     _, views = _ring(frames, w, h, ring_n, 64, 0xA5)
-    s = eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=True)
+    s = eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=True, two_stage=two_stage)
     got = _run_stream(eng, [s], views, frames, B, L, w)
+    s_status = s.corner_status()
     s.close()
     assert sorted(got) == list(range(1, nf))
     for p in range(1, nf):
         for k in range(L):
             assert _same_bits(got[p][0][k], want[p][k]), f"{mode} {w}x{h} B={B}: pair {p} level {k} differs from the plain sequence"
+    assert s_status == 0, f"status word {s_status:#x}: a corner shift left its patch"
     for p in (1, nf - 1):
         ref, _, _ = oracle.flow_pair(synth.to_3ch(frames[p - 1]), synth.to_3ch(frames[p]), L, win, mode, exact_sums=True)
         for k in range(L):

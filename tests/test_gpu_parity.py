@@ -649,7 +649,8 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 
-@pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (16, False), (1, True), (4, True), (8, True), (16, True)])
+@pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (16, False), (1, True), (4, True), (8, True), (16, True),
+                                          (1, "two_stage"), (2, "two_stage"), (4, "two_stage"), (8, "two_stage"), (16, "two_stage")])
 @pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
                                  (640, 480, 6, 9, "lk_float", 1, 14), (250, 186, 2, 7, "lk_float", 1, 7), (1280, 768, 7, 5, "lk_float", 2, 9),
                                  (320, 240, 3, 7, "lk_float", 2, 53)])  # the last: more than three full ticks of sixteen frames
@@ -659,12 +660,15 @@ def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch, borrow):
     Every pair must carry the bits of the plain sequence -- also for row-sharded sessions with local corner flows (third
     config: 4 logical ranks) and for frame counts that are not a multiple of B (the tail goes out when the stream is
     drained).  borrow: ofx_params.borrow_frames -- no level-0 copy, the LK and corner stages read the frame buffers
-    (padded, dirty padding) in place."""
+    (padded, dirty padding) in place; "two_stage": borrowed frames and ofx_params.stream_two_stage -- the corner blocks build
+    the patch pyramids they read, a pair is complete one tick earlier."""
     import torch
     from cuda_optical_flow_2_amd.parallel import ShardPlan
 
     w, h, L, win, mode, R, nf = cfg
     B = batch
+    two_stage = borrow == "two_stage"
+    borrow = bool(borrow)
     if B * L > 80:
         pytest.skip("stream_batch * levels exceeds OFX_MAX_LK_ITEMS")
     pitch = (w + 3) // 4 * 4 + 8
@@ -684,10 +688,10 @@ def test_multi_frame_stream_ticks_equal_plain_sequence(eng, cfg, batch, borrow):
     plain.close()
 
     if R == 1:
-        ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow)]
+        ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow, two_stage=two_stage)]
     else:
         ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B,
-                             borrow_frames=borrow) for r in range(R)]
+                             borrow_frames=borrow, two_stage=two_stage) for r in range(R)]
     got = {}
     for s in ranks:
         s.stream_begin()

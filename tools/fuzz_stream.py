@@ -21,7 +21,8 @@ def run(n_cfg: int, seed: int, verbose: bool = True) -> int:
       B = int(rng.choice([1, 2, 4, 8, 16]))
       if B * L > 80:
           B = 2
-      borrow = bool(rng.random() < 0.4)
+      borrow = bool(rng.random() < 0.5)
+      two_stage = borrow and bool(rng.random() < 0.5)   # ofx_params.stream_two_stage (needs borrowed frames)
       R = int(rng.choice([1, 1, 2, 3, 4]))
       if (h >> (L - 1)) < R:
           R = 1
@@ -38,7 +39,7 @@ def run(n_cfg: int, seed: int, verbose: bool = True) -> int:
       for i in range(nf):
           a = synth.smooth_pair(w, h, 1.1 * i, -0.7 * i, seed=it + 5)[1] if gen else synth.random_pair(w, h, seed=it * 100 + i)[0]
           frames.append(padded(a))
-      desc = f"{w}x{h} L{L} w{win} {mode} B{B} borrow={borrow} R{R} nf={nf} pitch={pitch}"
+      desc = f"{w}x{h} L{L} w{win} {mode} B{B} borrow={borrow} two_stage={two_stage} R{R} nf={nf} pitch={pitch}"
       try:
           plain = eng.Session(w, h, L, win, mode)
           plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
@@ -50,10 +51,10 @@ def run(n_cfg: int, seed: int, verbose: bool = True) -> int:
               plain.swap()
           plain.close()
           if R == 1:
-              ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow)]
+              ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow, two_stage=two_stage)]
           else:
               ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B,
-                                   borrow_frames=borrow) for r in range(R)]
+                                   borrow_frames=borrow, two_stage=two_stage) for r in range(R)]
           got, seen = {}, 0
           for s in ranks:
               s.stream_begin()
