@@ -561,6 +561,9 @@ def main():
                 if args.mode != "lk_float" or args.iters > 1:
                     kname += f"_{args.mode}_iters{args.iters}"
                 traffic = t.get(kname) if isinstance(t, dict) and driver is None else None  # measured for whole frames only
+                # (tools/pmc_run.py measures the default plan: two stages with the suggested frames per launch)
+                if args.path == "stream" and args.iters <= 1 and not (args.two_stage and args.batch == engine.suggest_stream_batch(w, h, levels, None, True, True)):
+                    traffic = None
             except Exception:
                 traffic = None
         borrowed = args.borrow and ((driver is None and args.path == "stream") or
@@ -598,9 +601,12 @@ def main():
                 "self_check": check_msg,
             },
             "roofline": {
-                "bound": "hbm", "kernel": (f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
+                "bound": "hbm", "kernel": ((f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
+                            f"{pairs_per_launch} pair(s) those frames complete, on patch pyramids the corner blocks build | fused LK of all levels of the "
+                            f"{pairs_per_launch} pair(s) before; bytes per pair = 10 B/px LK + 5 B/px pyramid)" if args.two_stage and driver is None else
+                            f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
                             f"{pairs_per_launch} pair(s) before | fused LK of all levels of the {pairs_per_launch} pair(s) before those; bytes per pair = "
-                            "10 B/px LK + 5 B/px pyramid)"
+                            "10 B/px LK + 5 B/px pyramid)")
                            if stream_like else
                            "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -56,13 +56,27 @@ __device__ __forceinline__ void patch_build_block(const PatchBuild &P, const Pat
     for (int k = 1; k <= P.n; ++k) {
         const int groups = (P.pw[k] + 3) / 4; // (the pitch covers the last group: it is the width rounded up to 64)
         const int per_frame = groups * P.ph[k];
-        for (int i = tid; i < 2 * per_frame; i += 256) {
-            const int f = i >= per_frame ? 1 : 0, j = i - f * per_frame;
-            const int y = j / groups, x0 = 4 * (j - y * groups);
-            const uint8_t *src = k == 1 ? S.src[f] : S.base + (size_t)f * (size_t)P.frame_stride + P.off[k - 1];
-            const int sp = k == 1 ? S.src_pitch[f] : P.pitch[k - 1];
-            const uint32_t v = down4(src, sp, 0, 0, P.ph[k - 1], P.pw[k - 1], P.pw[k], x0, y);
-            *reinterpret_cast<uint32_t *>(S.base + (size_t)f * (size_t)P.frame_stride + P.off[k] + (size_t)y * (size_t)P.pitch[k] + x0) = v;
+        // four groups per thread and pass, all their loads before the first store: the block is alone on its SIMDs' issue
+        // slots only in name (it shares them with LK waves), and a chain of one group at a time -- nine dependent loads, a
+        // store -- took ~60-90 us for the two patches of a 4K pair
+        for (int i0 = tid; i0 < 2 * per_frame; i0 += 4 * 256) {
+            uint32_t v[4];
+            uint8_t *dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                const bool on = i < 2 * per_frame;
+                const int ic = on ? i : i0;
+                const int f = ic >= per_frame ? 1 : 0, j = ic - f * per_frame;
+                const int y = j / groups, x0 = 4 * (j - y * groups);
+                const uint8_t *src = k == 1 ? S.src[f] : S.base + (size_t)f * (size_t)P.frame_stride + P.off[k - 1];
+                const int sp = k == 1 ? S.src_pitch[f] : P.pitch[k - 1];
+                v[u] = down4(src, sp, 0, 0, P.ph[k - 1], P.pw[k - 1], P.pw[k], x0, y);
+                dst[u] = on ? S.base + (size_t)f * (size_t)P.frame_stride + P.off[k] + (size_t)y * (size_t)P.pitch[k] + x0 : nullptr;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u]) *reinterpret_cast<uint32_t *>(dst[u]) = v[u];
         }
         __syncthreads();
     }

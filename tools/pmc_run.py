@@ -11,8 +11,9 @@ mode = sys.argv[3] if len(sys.argv) > 3 else "lk_float"
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 w, h, L, win = cfg
 p, n = synth.smooth_pair(w, h)
-B = engine.suggest_stream_batch(w, h, L, None, True)  # as bench.py runs it: borrowed frames from a ring of distinct buffers
-s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters)
+TWO = path == "stream" and iters <= 1  # as bench.py runs it: borrowed frames from a ring of distinct buffers, two stages
+B = engine.suggest_stream_batch(w, h, L, None, True, TWO)
+s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters, two_stage=TWO)
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     if path == "plain":
@@ -21,7 +22,7 @@ with torch.cuda.stream(st):
         for i in range(6):
             s.run_flow()
     else:
-        ring = (3 * max(B, 4) + 4 + 3) // 4 * 4
+        ring = ((2 if TWO else 3) * max(B, 4) + 4 + 3) // 4 * 4
         frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * (i % 4), 1.0 * (i % 4))[1]).cuda() for i in range(ring)]
         s.stream_begin()
         for i in range(10 * B):

@@ -12,20 +12,21 @@ name = sys.argv[1] if len(sys.argv) > 1 else "4k"
 worlds = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
 w, h, L, win = WORK[name]
 frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1]).cuda() for i in range(4)]
-BORROW = os.environ.get("OFX_SIM_BORROW", "1") == "1"  # as bench.py: the frames are read in place from a ring of distinct buffers
+BORROW = os.environ.get("OFX_SIM_BORROW", "1") == "1"
+TWO = os.environ.get("OFX_SIM_TWO_STAGE", "0") == "1"  # ofx_params.stream_two_stage  # as bench.py: the frames are read in place from a ring of distinct buffers
 st = torch.cuda.Stream()
 torch.cuda.set_stream(st)
 for N in worlds:
     res, host = [], []
-    batch = int(os.environ.get("OFX_SIM_BATCH", "0")) or engine.suggest_stream_batch(w, h, L, ShardPlan(w, h, L, win, 0, N) if N > 1 else None, BORROW)
-    ring = (3 * max(batch, 4) + 4 + 3) // 4 * 4
+    batch = int(os.environ.get("OFX_SIM_BATCH", "0")) or engine.suggest_stream_batch(w, h, L, ShardPlan(w, h, L, win, 0, N) if N > 1 else None, BORROW, TWO)
+    ring = ((2 if TWO else 3) * max(batch, 4) + 4 + 3) // 4 * 4
     while len(frames) < ring:
         frames.append(frames[len(frames) % 4].clone())
     # a tick's frames go down in one call, as in bench.py (tick j takes ring buffers j*B .. j*B + B - 1 modulo the ring)
     groups = [engine.FrameGroup([frames[(j * batch + k) % ring] for k in range(batch)]) for j in range(math.lcm(ring, batch) // batch)]
     for r in sorted({0, N // 2, N - 1}):
         s = engine.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, N), local_corner=True,
-                           stream_batch=batch, borrow_frames=BORROW)
+                           stream_batch=batch, borrow_frames=BORROW, two_stage=TWO)
         s.stream_begin()
         t_ramp = time.perf_counter() + 0.2  # untimed: the first ~10 ms after start-up run 15-20 % slow (see bench.py)
         while time.perf_counter() < t_ramp:
@@ -43,4 +44,4 @@ for N in worlds:
         s.close()
     worst = max(t for _, t in res)
     print(f"{name} N={N}: " + "  ".join(f"rank {r}: {t:.1f} us" for r, t in res) + f"  -> {w * h / worst:.0f} Mpix/s if all ranks run like the slowest"
-          f"  (host enqueue {max(host):.1f} us per frame; {batch} frames per launch, {'borrowed' if BORROW else 'copied'} frames, ring {ring})")
+          f"  (host enqueue {max(host):.1f} us per frame; {batch} frames per launch, {'borrowed' if BORROW else 'copied'} frames, ring {ring}{', two stages' if TWO else ''})")
