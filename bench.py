@@ -445,9 +445,11 @@ def main():
         dist.barrier()
 
     # ---- generic stream leg for the extras: wall-clock throughput + event-timed launches ---------------------------------
-    def stream_leg(wl, mode, batch, borrow, ring, steps, events=True):
+    def stream_leg(wl, mode, batch, borrow, ring, steps, events=True, two_stage=None):
         w2, h2, l2, win2 = wl
-        s2 = engine.Session(w2, h2, l2, win2, mode, device=local_rank, stream_batch=batch, borrow_frames=borrow)
+        two_stage = (args.two_stage and borrow) if two_stage is None else two_stage   # like the main run wherever the frames are borrowed
+        assert len(ring) >= (2 if two_stage else 3) * batch + 1 or not borrow, "the ring is too short for borrowed frames"
+        s2 = engine.Session(w2, h2, l2, win2, mode, device=local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage)
         s2.stream_begin()
         fd = StreamFeed(s2.stream_submit_frames, ring, batch)
         t_end = time.perf_counter() + 0.15
@@ -710,7 +712,7 @@ def main():
                 # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
                 # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
                 b3 = engine.suggest_stream_batch(w, h, levels, None, False)
-                r3 = stream_leg((w, h, levels, window), args.mode, b3, False, d_ring, args.steps)
+                r3 = stream_leg((w, h, levels, window), args.mode, b3, False, d_ring[:16] if len(d_ring) > 16 else d_ring, args.steps)
                 r3["workload"] = f"as value, but the session copies level 0 of every frame ({b3} frames per launch)"
                 extra["stream_with_copied_frames"] = r3
                 # cache-cold inputs: the ring is long enough that neither the frames nor the session's image sets survive in the
@@ -731,14 +733,14 @@ def main():
                 r8["workload"] = "as value, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
                 extra["fast_solve"] = r8
                 # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
-                bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow)
+                bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow, args.two_stage)
                 r7 = stream_leg((w, h, levels, window), "compat_cpu", bc, args.borrow, d_ring if bc == args.batch else make_ring(d_frames, ring_size(bc)), args.steps)
                 r7["workload"] = f"as value, mode compat_cpu (OptFlowCPU.cpp:312-399 bug for bug; stream path, {bc} frames per launch)"
                 extra["compat_cpu"] = r7
             if args.path == "stream" and args.workload == "4k":
                 # the metric names 1080p pairs next to 4K ones (BASELINE.json): the same pipeline on the 1080p configuration
                 wl5 = WORKLOADS["1080p"]
-                b5 = engine.suggest_stream_batch(*wl5[:3], None, True)  # (the leg reads its frames in place)
+                b5 = engine.suggest_stream_batch(*wl5[:3], None, True, args.two_stage)  # (the leg reads its frames in place)
                 f5 = make_ring([torch.from_numpy(synth.smooth_pair(wl5[0], wl5[1], 2.0 * i * mx, 1.0 * i * my)[1]).cuda() for i in range(nframes)],
                                ring_size(b5))
                 r5 = stream_leg(wl5, args.mode, b5, True, f5, args.steps)
