@@ -1089,7 +1089,7 @@ def test_determinant_guard(eng, oracle):
     st.close()
 
 
-@pytest.mark.parametrize("borrow", [False, True])
+@pytest.mark.parametrize("borrow", [False, True, "two_stage"])
 @pytest.mark.parametrize("cfg", [(640, 480, 3, 9, 3, 1), (640, 480, 4, 7, 5, 2), (1280, 720, 4, 9, 2, 4), (256, 192, 2, 5, 4, 8)])
 def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg, borrow):
     """iters > 1 through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every further iteration is
@@ -1110,7 +1110,7 @@ def test_streamed_refinement_iterations_equal_the_pair_at_a_time_path(eng, cfg, 
         want[i] = [plain.flow_host(k) for k in range(L)]
         plain.swap()
     plain.close()
-    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B, borrow_frames=borrow)
+    s = eng.Session(w, h, L, win, "lk_float", iters=iters, stream_batch=B, borrow_frames=bool(borrow), two_stage=borrow == "two_stage")
     s.stream_begin()
     got, seen = {}, 0
 
