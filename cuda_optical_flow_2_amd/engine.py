@@ -55,13 +55,15 @@ class FrameGroup:
 def suggest_stream_batch(width: int, height: int, levels: int, shard=None, borrow_frames: bool = False, two_stage: bool = False) -> int:
     """Frames per launch (ofx_params.stream_batch) for a throughput-bound stream on MI355X: the largest B in {16, 8, 4} the
     launch can carry (OFX_MAX_LK_ITEMS = 80 (pair, level) items) whose cyclic working set stays inside the 256 MB Infinity
-    Cache, else 2.  The working set is what lives between a frame's arrival and its last use: the session's 3B+2 image sets (the
-    whole pyramid, or levels >= 1 only with borrow_frames) plus the caller's ring of frames (borrow_frames needs at
-    least 3B+1 buffers -- include/ofx.h states the lifetime rule: frame f's buffer is read until the launch enqueued by the
-    submit of frame f+3B has run --; the estimate assumes the ring bench.py uses, 3B+4 rounded up to a multiple of four).  Measured: the fused level kernel
-    runs ~25 % slower when its image rows come from HBM instead of that cache -- 4K, copied frames: 2 / 4 frames per launch
-    = 222k / 197k Mpix/s; borrowed frames: 4 / 8 = 251k / 219k; 1080p takes 16 (8 / 16 frames per launch = 227k-247k / 258k-267k), the ranks of a
-    sharded pair 8 (sixteen measured no better there: tools/shard_sim.py)."""
+    Cache, else 2.  The working set is what lives between a frame's arrival and its last use, d = 3 ticks later (2 with
+    two_stage = ofx_params.stream_two_stage): the session's dB+2 image sets (the whole pyramid, or levels >= 1 only with
+    borrow_frames) plus the caller's ring of frames (borrow_frames needs at least dB+1 buffers -- include/ofx.h states the
+    lifetime rule: frame f's buffer is read until the launch enqueued by the submit of frame f+dB has run --; the estimate
+    assumes the ring bench.py uses, dB+4 rounded up to a multiple of four).  Measured: the fused level
+    kernel runs ~25 % slower when its image rows come from HBM instead of that cache -- 4K, copied frames: 2 / 4 frames per
+    launch = 222k / 197k Mpix/s; borrowed frames in three stages: 4 / 8 = 251-264k / 219k, in two stages: 8 = 274-280k; 1080p
+    takes 16 (8 / 16 frames per launch = 227k-247k / 258k-267k), the ranks of a sharded pair 8 (sixteen measured no better
+    there: tools/shard_sim.py)."""
     rows = [(height >> k) if shard is None else (shard.buf[k][1] - shard.buf[k][0]) for k in range(levels)]
     level_bytes = [(width >> k) * rows[k] for k in range(levels)]
     depth = 2 if two_stage else 3   # ticks a frame stays in use (ofx_params.stream_two_stage)
