@@ -351,10 +351,10 @@ typedef struct ofx_params {
     /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame
      * buffers handed to ofx_session_stream_submit, and the pyramid stage only writes levels 1 and up.
      * LIFETIME RULE (the one statement of it; INTEGRATION.md, DESIGN.md and engine.py quote it): the buffer of frame f
-     * (frames counted from 0, B = stream_batch) is last read by the launch that the submit of frame f + 3B enqueues, at the
-     * latest.  It may be rewritten (a) by work enqueued on the SAME stream after that submit call, or (b) from the host or
+     * (frames counted from 0, B = stream_batch) is last read by the launch that the submit of frame f + dB enqueues, at the
+     * latest, where d = 3, or 2 with stream_two_stage (below).  It may be rewritten (a) by work enqueued on the SAME stream after that submit call, or (b) from the host or
      * another stream once that launch has COMPLETED -- the submit call returning is not enough.  A producer that writes
-     * frame g into its buffer on the stream, right before submitting it, therefore needs a ring of at least 3B + 1
+     * frame g into its buffer on the stream, right before submitting it, therefore needs a ring of at least dB + 1
      * buffers; one that writes asynchronously needs as many more as it has launches in flight.
      * Saves 2 bytes per level-0 pixel of HBM traffic per frame and a third of the pipeline's cache working set
      * (DESIGN.md section 4.3).  0 = copy (any buffer lifetime).
