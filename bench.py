@@ -33,6 +33,7 @@ WORKLOADS = {  # BASELINE.json configs: (width, height, levels, window)
     "8k": (7680, 4320, 6, 15),
 }
 BASELINE_ITERS = {"vga": 3, "1080p": 5, "4k": 5, "8k": 10}  # the "iters" of BASELINE.json's configs
+OFX_TWO_STAGE_MIN_BATCH = 5   # frames per launch from which ofx_params.stream_two_stage pays at 4K (measured)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # Algorithmic bytes (each array once at its stored size)
 LK_BYTES_PER_PX = 10       # fused level kernel: 2 u8 read + one (u,v) float pair written
@@ -155,8 +156,8 @@ def main():
     ap.add_argument("--three-stage", action="store_true",
                     help="stream path: the three-tick pipeline (pyramid | corner a tick later | LK two ticks later) instead of "
                          "ofx_params.stream_two_stage, which an unsharded stream with borrowed frames uses by default")
-    ap.add_argument("--batch", type=int, default=0, choices=[0, 1, 2, 4, 8, 16],
-                    help="stream path: frames per launch (ofx_params.stream_batch); a step is still one frame.  0 = "
+    ap.add_argument("--batch", type=int, default=0, choices=list(range(0, 17)),
+                    help="stream path: frames per launch (ofx_params.stream_batch) = frames per step.  0 = "
                          "engine.suggest_stream_batch: by the working set of the pipeline (4K: 4 on one GPU, 8 per rank of a sharded pair)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
@@ -178,11 +179,15 @@ def main():
         bw, bh, bl, bwin = WORKLOADS[args.workload]
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
         args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow, args.two_stage)
-    while args.batch > 1 and (args.steps % args.batch or
-                              args.batch * WORKLOADS[args.workload][2] > 80):  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
-        args.batch //= 2
-    # (the warm-up is rounded UP to whole ticks -- a few more untimed steps -- so that only K constrains the frames per launch)
-    warmup_steps = (args.warmup + args.batch - 1) // args.batch * args.batch
+    while args.batch > 1 and args.batch * WORKLOADS[args.workload][2] > 80:  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
+        args.batch -= 1
+    # (with few frames per launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
+    # the launch waits for: three stages are the better plan there)
+    if args.two_stage and args.batch < OFX_TWO_STAGE_MIN_BATCH:
+        args.two_stage = False
+    # A STEP of the stream path is one tick = one launch = args.batch frames (one pass of the hot path over one batch of
+    # input); of the pair-at-a-time paths one pair.  W and K count steps; every per-frame figure of the line says so.
+    warmup_steps = args.warmup
 
     import numpy as np
     import torch
@@ -258,10 +263,15 @@ def main():
             n = len(ring)
             self.groups = [engine.FrameGroup([ring[(j * batch + k) % n] for k in range(batch)]) for j in range(math.lcm(n, batch) // batch)]
 
-        def step(self, _i=None):
+        def step(self, _i=None):   # one frame
             self.frames_in += 1
             if self.frames_in % self.batch == 0:
                 self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
+
+        def tick(self, _i=None):   # a whole tick: self.batch frames, one launch
+            assert self.frames_in % self.batch == 0
+            self.frames_in += self.batch
+            self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
 
     feed = None
     if not distributed:
@@ -277,8 +287,8 @@ def main():
             # pipeline is full
             sess.stream_begin()
             feed = StreamFeed(sess.stream_submit_frames, d_ring, args.batch)
-            step = feed.step
-            for i in range(3 * args.batch):
+            step = feed.tick
+            for i in range(3):   # (fill the pipeline)
                 step(i)
         elif args.path == "staged":
             # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
@@ -308,8 +318,8 @@ def main():
         if args.shard_corner == "local":
             driver.stream_begin()
             feed = StreamFeed(driver.stream_submit_frames, d_ring, args.batch)
-            step = feed.step
-            for i in range(3 * args.batch):
+            step = feed.tick
+            for i in range(3):   # (fill the pipeline)
                 step(i)
         else:
             driver.push_frame(d_frames[0])
@@ -337,14 +347,12 @@ def main():
     ramp_s = float(os.environ.get("OFX_BENCH_RAMP_S", "0.3"))
     t_ramp = time.perf_counter() + ramp_s
     i_ramp = 0
+    fps = args.batch if feed is not None else 1   # frames (pairs) per step
     while time.perf_counter() < t_ramp:
-        for _ in range(64):
+        for _ in range(max(8, 64 // fps)):
             step(i_ramp)
             i_ramp += 1
         torch.cuda.synchronize()
-    if feed is not None:   # finish the tick the ramp may have left half full, so that the timed steps are whole ticks
-        while feed.frames_in % args.batch:
-            step(0)
     for i in range(warmup_steps):
         step(i)
     fence()
@@ -356,8 +364,8 @@ def main():
     dt = time.perf_counter() - t0
     # pass 2 -- the dominant kernel's duration: the same steps again with a pair of HIP events recorded around every
     # launch on the stream it runs on (two extra packets per launch, so this pass is not the one timed above)
-    # (at least 400 steps, so that a short driver run -- K = 20 is five launches -- still averages over ~100 launches)
-    roof_steps = max(args.steps, 400 // args.batch * args.batch)
+    # (at least ~100 launches, so that a short driver run -- K = 20 -- still gives a stable average)
+    roof_steps = max(args.steps, -(-400 // args.batch) if feed is not None else 400)
     sess.timing(roof_steps * (2 * max(1, args.iters) + 3))
     for i in range(roof_steps):
         step(warmup_steps + args.steps + i)
@@ -496,13 +504,13 @@ def main():
             for i in range(16 * b4):
                 fd4.step()
             torch.cuda.synchronize()
-        n4 = args.steps // b4 * b4 or b4
+        n4 = max(args.steps * fps // b4 * b4, b4)   # as many frames as the timed region held
         fence()
         t0 = time.perf_counter()
         for i in range(n4):
             fd4.step()
         fence()
-        dt_indep = max_over_ranks(time.perf_counter() - t0) * args.steps / n4
+        dt_indep = max_over_ranks(time.perf_counter() - t0) / n4   # seconds per frame and rank
         s4.close()
         del r4
         # north_star's literal formulation, so that a scaling run shows RCCL carrying the halos: every rank holds only its own
@@ -548,7 +556,7 @@ def main():
             # and tagged (ofx_session_timing_read_kind); bytes per SURVEY 8d: 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid
             pair_alg = ((LK_BYTES_PER_PX + (args.iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * own_px +
                         PYR_BYTES_PER_DST_PX * sum(level_px(w, h, levels, own_rows)[1:]))
-            us_pair = sum(v[0] * v[2] for v in kinds.values() if v[2]) / roof_steps
+            us_pair = sum(v[0] * v[2] for v in kinds.values() if v[2]) / (roof_steps * fps)
             iters_pair = {"algorithmic_bytes_per_pair": pair_alg, "kernel_us_per_pair": round(us_pair, 2),
                           "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in kinds.items() if v[2]}}
             lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, roof_steps
@@ -572,11 +580,12 @@ def main():
                                     (driver is not None and args.shard_corner == "local" and args.shard_halo != "exchange"))
         out = {
             "metric": "Mpix/s dense LK flow",
-            "value": round(w * h / (ms * 1e-3) / 1e6, 1),
+            "value": round(fps * w * h / (ms * 1e-3) / 1e6, 1),
             "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 5),
-            "frames_per_s": round(1e3 / ms, 1),
+            "frames_per_step": fps,
+            "frames_per_s": round(fps * 1e3 / ms, 1),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -585,6 +594,8 @@ def main():
             "self_check": "skipped" if check_msg.startswith("SKIPPED") else "ok",
             "config": {
                 "untimed_clock_ramp_s": ramp_s, "warmup_steps_run": warmup_steps,
+                "step": (f"one tick of the stream pipeline = one launch = {fps} frames (pairs): K = {args.steps} steps are {args.steps * fps} pairs"
+                         if stream_like else "one frame pair"),
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
                             f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
@@ -796,12 +807,12 @@ def main():
                 del img, gray, filt
             extra["frontend"] = fe
         if dt_indep is not None:
-            ms4 = dt_indep / args.steps * 1e3
+            ms4 = dt_indep * 1e3
             extra["independent_pairs_per_rank"] = {
                 "workload": f"every one of the {world} rank(s) runs the unsharded stream pipeline on its own frame pairs (no sharding, no "
                             "communication): aggregate pairs/s, weak scaling, latency per pair as on one GPU",
                 "value": round(world * w * h / (ms4 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step_per_rank": round(ms4, 5),
-                "steps_per_rank": args.steps}
+                "frames_per_rank": n4}
         if dt_exch is not None:
             if dt_exch[0] is None:
                 extra["halo_exchange"] = {"skipped": dt_exch[2]}

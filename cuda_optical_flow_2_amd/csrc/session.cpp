@@ -132,9 +132,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
                 "ofx_session_create: bad mode %d", p->mode);
     OFX_REQUIRE(p->min_det >= 0.0f, "ofx_session_create: min_det must be >= 0 (0 = the reference's unguarded solve)");
     OFX_REQUIRE(p->iters >= 0 && p->iters <= 64, "ofx_session_create: iters %d out of range", p->iters);
-    OFX_REQUIRE(p->stream_batch == 0 || p->stream_batch == 1 || p->stream_batch == 2 || p->stream_batch == 4 ||
-                    p->stream_batch == 8 || p->stream_batch == 16,
-                "ofx_session_create: stream_batch %d (0, 1, 2, 4, 8 or 16)", p->stream_batch);
+    OFX_REQUIRE(p->stream_batch >= 0 && p->stream_batch <= OFX_STREAM_MAX_BATCH, "ofx_session_create: stream_batch %d (0 .. %d)", p->stream_batch,
+                OFX_STREAM_MAX_BATCH);
     OFX_REQUIRE(p->stream_batch * p->levels <= OFX_MAX_LK_ITEMS, "ofx_session_create: stream_batch %d needs levels <= %d",
                 p->stream_batch, OFX_MAX_LK_ITEMS / (p->stream_batch > 0 ? p->stream_batch : 1));
     OFX_REQUIRE(!p->stream_two_stage || p->borrow_frames, "ofx_session_create: stream_two_stage needs borrow_frames (the corner stage reads "

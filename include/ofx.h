@@ -345,7 +345,7 @@ typedef struct ofx_params {
      * the patch; ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
-    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 / 4 / 8 / 16 = one launch per that many frames
+    /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 .. 16 = one launch per that many frames
      * (see ofx_session_stream_submit); stream_batch * levels <= OFX_MAX_LK_ITEMS. */
     int stream_batch;
     /* Stream pipeline without its own copy of level 0: the LK and corner stages read level 0 straight from the frame
