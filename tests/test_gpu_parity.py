@@ -650,7 +650,8 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
 
 
 @pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (16, False), (1, True), (4, True), (8, True), (16, True),
-                                          (1, "two_stage"), (2, "two_stage"), (4, "two_stage"), (8, "two_stage"), (16, "two_stage")])
+                                          (1, "two_stage"), (2, "two_stage"), (4, "two_stage"), (8, "two_stage"), (16, "two_stage"),
+                                          (3, False), (5, True), (5, "two_stage"), (10, "two_stage")])   # (any B up to 16 is accepted)
 @pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 1, 12), (640, 480, 3, 5, "compat_cpu", 1, 9), (1920, 1088, 5, 7, "lk_float", 4, 11),
                                  (640, 480, 6, 9, "lk_float", 1, 14), (250, 186, 2, 7, "lk_float", 1, 7), (1280, 768, 7, 5, "lk_float", 2, 9),
                                  (320, 240, 3, 7, "lk_float", 2, 53)])  # the last: more than three full ticks of sixteen frames
