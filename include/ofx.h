@@ -418,9 +418,10 @@ int ofx_session_stage_shift(ofx_session *s, void *aux_stream);
 int ofx_session_solve_staged(ofx_session *s, void *stream);
 int ofx_session_aux_stream(ofx_session *s, void **stream);
 /* Stream pipeline (highest throughput): ONE launch (ofx_stream_launch) per tick of B = ofx_params.stream_batch frames
- * (1, 2, 4 or 8), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
+ * (1 .. 16), in which the pyramids of those frames, the corner flows of the B pairs before and the fused LK (shift
  * included) of the B pairs before that run side by side.  With B = 1 every call launches and the flow of pair p (frame
- * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  With B > 1 only every B-th call launches,
+ * p-1 -> frame p, frames counted from 0) is written by the launch of frame p+2.  (ofx_params.stream_two_stage: the corner
+ * flows of the pairs the tick's own frames complete, the LK of the B pairs before -- everything one tick earlier.)  With B > 1 only every B-th call launches,
  * for the B frames received since the last launch (the others are remembered: their buffers must stay unmodified until
  * that launching call has returned); pairs complete B at a time, one tick later.  *completed_pair receives the HIGHEST
  * pair complete after the call in `stream` order (all lower ones are complete too; -1 when the call completed none); the
