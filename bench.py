@@ -33,7 +33,7 @@ WORKLOADS = {  # BASELINE.json configs: (width, height, levels, window)
     "8k": (7680, 4320, 6, 15),
 }
 BASELINE_ITERS = {"vga": 3, "1080p": 5, "4k": 5, "8k": 10}  # the "iters" of BASELINE.json's configs
-OFX_TWO_STAGE_MIN_BATCH = 5   # frames per launch from which ofx_params.stream_two_stage pays at 4K (measured)
+OFX_TWO_STAGE_MIN_PIXELS = 30e6   # level-0 pixels per launch from which ofx_params.stream_two_stage pays (4K: five frames; measured)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 # Algorithmic bytes (each array once at its stored size)
 LK_BYTES_PER_PX = 10       # fused level kernel: 2 u8 read + one (u,v) float pair written
@@ -181,9 +181,9 @@ def main():
         args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow, args.two_stage)
     while args.batch > 1 and args.batch * WORKLOADS[args.workload][2] > 80:  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
         args.batch -= 1
-    # (with few frames per launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
+    # (in a short launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
     # the launch waits for: three stages are the better plan there)
-    if args.two_stage and args.batch < OFX_TWO_STAGE_MIN_BATCH:
+    if args.two_stage and args.batch * WORKLOADS[args.workload][0] * WORKLOADS[args.workload][1] < OFX_TWO_STAGE_MIN_PIXELS:
         args.two_stage = False
     # A STEP of the stream path is one tick = one launch = args.batch frames (one pass of the hot path over one batch of
     # input); of the pair-at-a-time paths one pair.  W and K count steps; every per-frame figure of the line says so.
