@@ -183,8 +183,8 @@ def main():
         args.batch -= 1
     # (in a short launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
     # the launch waits for: three stages are the better plan there)
-    if args.two_stage and args.batch * WORKLOADS[args.workload][0] * WORKLOADS[args.workload][1] < OFX_TWO_STAGE_MIN_PIXELS:
-        args.two_stage = False
+    if args.two_stage and (args.batch < 5 or args.batch * WORKLOADS[args.workload][0] * WORKLOADS[args.workload][1] < OFX_TWO_STAGE_MIN_PIXELS):
+        args.two_stage = False   # (8K, two frames per launch: the patch of six levels and a 15x15 window is 544 pixels wide -- 129k vs 217k Mpix/s)
     # A STEP of the stream path is one tick = one launch = args.batch frames (one pass of the hot path over one batch of
     # input); of the pair-at-a-time paths one pair.  W and K count steps; every per-frame figure of the line says so.
     warmup_steps = args.warmup
