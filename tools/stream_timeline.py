@@ -8,11 +8,12 @@ from cuda_optical_flow_2_amd import engine, lib, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 w, h, L, win = 3840, 2160, 5, 9
 frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * i, 1.0 * i)[1]).cuda() for i in range(4)]
-RING = int(os.environ.get("OFX_TL_RING", str((3 * max(B, 4) + 4 + 3) // 4 * 4)))  # distinct source buffers, as bench.py
+RING = int(os.environ.get("OFX_TL_RING", str(((2 if B >= 5 and os.environ.get("OFX_TL_TWO_STAGE", "1") == "1" else 3) * max(B, 4) + 4 + 3) // 4 * 4)))  # distinct source buffers, as bench.py
 frames = [frames[i % 4] if i < 4 else frames[i % 4].clone() for i in range(RING)]
 BORROW = os.environ.get("OFX_TL_BORROW", "1") == "1"  # as bench.py
+TWO = os.environ.get("OFX_TL_TWO_STAGE", "1" if B >= 5 else "0") == "1"  # ofx_params.stream_two_stage, as bench.py from five frames per launch
 st = torch.cuda.Stream(); torch.cuda.set_stream(st)
-s = engine.Session(w, h, L, win, "lk_float", stream_batch=B, borrow_frames=BORROW)
+s = engine.Session(w, h, L, win, "lk_float", stream_batch=B, borrow_frames=BORROW, two_stage=TWO and BORROW)
 s.stream_begin()
 for i in range(10 * B):
     s.stream_submit(frames[i % RING])
@@ -103,3 +104,8 @@ allk = key
 for k in late:
     ws = widx[(allk == k) & m]
     print(f"  late SIMD {k}: last end {last_by[k]:.1f}, pyramid waves {pyr_cnt.get(k, 0)}, LK waves {[(int(i), round(float(dur[i]), 1), round(float(us[sl][i, 0]), 1)) for i in ws]}")
+# is block b on XCD b mod 8?  (what an XCD-aware plan would assume)
+blk = np.arange(len(raw)) // 4
+okm = ok
+agree = float(np.mean((xcc[okm] == (blk[okm] % 8))))
+print(f"waves whose XCC_ID == block index mod 8: {100 * agree:.2f} %")
