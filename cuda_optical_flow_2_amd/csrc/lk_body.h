@@ -705,6 +705,9 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
     }
 
     int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
+#ifdef OFX_X_SKELETON // timing experiment: row loads, the wait, the LDS exchange and the streaming stores -- nothing else
+    uint32_t skel = 0u;
+#endif
 
     auto body = [&](auto K, int s) {
         constexpr int k = decltype(K)::value; // s mod 3
@@ -743,16 +746,25 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
         uint32_t rowm = ((yy >= 0 && yy < A.h) ? 0x00000001u : 0u) | ((yh >= 0 && yh < A.h) ? him : 0u);
         if constexpr (INTERIOR) rowm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowm); // one scalar multiplier pair for all columns
         const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
+#ifndef OFX_X_SKELETON
         s2 ix[4], iy[4], it[4];
         derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
         accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
+#else
+        (void)mm;
+#endif
         // row yy - 1 is done with: its slot takes row yy + 2 once the step's arithmetic is over
         // (the barrier keeps the scheduler from hoisting these few ALU ops -- and with them the wait -- up to the loads;
         // pin_row keeps the sink passes from moving them down into the next step, below its loads)
         auto take_rows = [&]() {
             __builtin_amdgcn_sched_barrier(0);
+#ifdef OFX_X_SKELETON
+            skel ^= finish_row(pf_ip) ^ finish_next(pf_in) ^ finish_row(pf_op) ^ finish_next(pf_on);
+            asm volatile("" : "+v"(skel));
+#else
             unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
             pin_row(wp[k]);
+#endif
         };
 
         // ---- emit output row y = yy - R ------------------------------------------------------------------------
@@ -762,7 +774,10 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
         f32x4 xlo, xhi; // this lane's two chunks of the exchanged row (only defined, and only used, in emitting steps: the
         asm("" : "=v"(xlo), "=v"(xhi)); // empty asm stands in for an initialisation that would cost 8 v_mov per step)
         if (emit) {
-#ifdef OFX_X_NOHBOX // timing experiments (OFX_BUILD_DEFS): what a stage costs is what the launch gains without it
+#ifdef OFX_X_SKELETON
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hxx[j] = hyy[j] = hxy[j] = hxt[j] = hyt[j] = (int)skel + j;
+#elif defined(OFX_X_NOHBOX) // timing experiments (OFX_BUILD_DEFS): what a stage costs is what the launch gains without it
 #pragma unroll
             for (int j = 0; j < 4; ++j) hxx[j] = vxx[j], hyy[j] = vyy[j], hxy[j] = vxy[j], hxt[j] = vxt[j], hyt[j] = vyt[j];
 #else
@@ -774,7 +789,7 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
 #endif
             if constexpr (!SUMS) {
                 // every lane solves (the halo lanes' results are dropped): no divergence before the rows are taken
-#ifdef OFX_X_NOSOLVE
+#if defined(OFX_X_NOSOLVE) || defined(OFX_X_SKELETON)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uv[2 * j] = __int_as_float(hxx[j] ^ hxy[j] ^ hxt[j]);

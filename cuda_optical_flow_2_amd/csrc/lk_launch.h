@@ -3,6 +3,7 @@
 // family -- the radii 1..12 of a family are ~90 s of hipcc on one core, six families in parallel are ~40 s.
 #pragma once
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "corner_body.h"
@@ -21,7 +22,8 @@ struct StreamArgs {
     CornerHead corner[OFX_STREAM_MAX_BATCH];
     CornerLevel corner_lv[OFX_MAX_LK_ITEMS]; // the chains' levels, flat: chain i's level k at [corner[i].lv0 + k]
     // two-stage pipeline: the corner blocks build the patch pyramids their chains read (same geometry for every chain)
-    PatchBuild patch;
+    PatchBuild patch;   // geometry of the patch planes (n > 0 when the corner blocks build and / or relocate them)
+    int patch_build;    // the corner blocks build the patch pyramids of both frames first (two-stage pipeline)
     PatchBuildSlot patch_slot[OFX_STREAM_MAX_BATCH];
     // blocks [0, OFX_STREAM_MAX_BATCH) = one corner wave each; [.., first[0]) LK (four waves per block);
     // [first[i], first[i+1]) pyramid stage i (four marching waves per block, pyr_march.h).
@@ -94,8 +96,12 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
         // from 3 to 0 as they advance, lk_body.h)
         __builtin_amdgcn_s_setprio(3);
         if (b < S.n_corner) {
-            if (S.patch.n > 0) patch_build_block(S.patch, S.patch_slot[b], tid); // (all 256 threads; ends with a barrier)
-            if (wv == 0) corner_wave<MODE, FAST>(S.corner[b], S.corner_lv + S.corner[b].lv0, tid & 63, reinterpret_cast<float *>(lds), lds + kCornerScratch);
+            if (S.patch_build) patch_build_block(S.patch, S.patch_slot[b], tid); // (all 256 threads; ends with a barrier)
+            // the chain (wave 0) with its repair (all four waves: corner_block; without relocated planes -- S.corner[b].reloc == NULL --
+            // the other waves only keep the barriers company).  ONE inlined copy of the chain per kernel: with two (corner_wave
+            // next to corner_block) hipcc 7.2 fails with "illegal VGPR to SGPR copy" in the LK branch's pinned scalars.
+            corner_block<MODE, FAST>(S.corner[b], S.corner_lv + S.corner[b].lv0, S.patch, tid, wv, reinterpret_cast<float *>(lds), lds + kCornerScratch,
+                                     reinterpret_cast<int *>(lds + kCornerScratch - 32));
         }
     } else if (b < S.first[0]) {
         lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLds);
@@ -128,18 +134,64 @@ int env_int(const char *name, int dflt)
 // `capacity` (lk_wave_target), but at least `min_h` so the 2R priming rows of a strip stay a minor cost.
 // The grid is sized to fit in ONE residency round: every wave runs for the whole kernel, so a second, partly filled
 // round would nearly double the run time.
+// Age skew (OFX_LK_SKEW="p0,p1,p2,p3", per cent): a SIMD serves its waves oldest first, and a wave's age rank on its SIMD is the
+// quartile of its block index (every CU receives one block of each quartile in turn).  The strips of the items in quartile q are
+// cut skew[q] per cent of the common height, so that the waves served first carry more rows.  Exact integer sums: the result
+// does not depend on where the strips are cut.
+inline const double *lk_skew()
+{
+    static double sk[4] = {1.0, 1.0, 1.0, 1.0};
+    static const bool init = [] {
+        const char *e = getenv("OFX_LK_SKEW");
+        int v[4];
+        if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int i = 0; i < 4; ++i) sk[i] = v[i] > 10 ? v[i] / 100.0 : 1.0;
+        return true;
+    }();
+    (void)init;
+    return sk;
+}
+
 template <int R>
 int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
 {
     using G = TileGeom<R>;
     const int min_h = env_int("OFX_LK_MIN_STRIP", 8);
+    const double *skew = lk_skew();
+    const bool skewed = skew[0] != 1.0 || skew[1] != 1.0 || skew[2] != 1.0 || skew[3] != 1.0;
     int max_rows = 1;
     for (int i = 0; i < n; ++i) max_rows = lv[i].rows_out > max_rows ? lv[i].rows_out : max_rows;
-    int strip_h = min_h;
-    for (; strip_h < max_rows; ++strip_h) {
-        long waves = 0;
-        for (int i = 0; i < n; ++i) waves += (long)ofx_div_up(lv[i].a.w, G::OUT_W) * ofx_div_up(lv[i].rows_out, strip_h);
-        if (waves <= (long)capacity) break;
+    int quart[OFX_MAX_LK_ITEMS] = {0};
+    auto height = [&](int i, int H) {
+        int hi = skewed ? (int)(H * skew[quart[i]] + 0.5) : H;
+        hi = hi < min_h ? min_h : hi;
+        return hi < lv[i].rows_out ? hi : lv[i].rows_out;
+    };
+    auto item_waves = [&](int i, int H) { return (long)ofx_div_up(lv[i].a.w, G::OUT_W) * ofx_div_up(lv[i].rows_out, height(i, H)); };
+    auto solve_h = [&]() {
+        int H = min_h;
+        for (; H < max_rows; ++H) {
+            long waves = 0;
+            for (int i = 0; i < n; ++i) waves += item_waves(i, H);
+            if (waves <= (long)capacity) break;
+        }
+        return H;
+    };
+    int strip_h = solve_h();
+    if (skewed) { // the quartile of an item = where the middle of its block range falls; two rounds settle it
+        for (int round = 0; round < 2; ++round) {
+            long total = 0, pos = 0;
+            for (int i = 0; i < n; ++i) total += item_waves(i, strip_h);
+            int q_new[OFX_MAX_LK_ITEMS];
+            for (int i = 0; i < n; ++i) {
+                const long wv = item_waves(i, strip_h);
+                const int q = (int)((4 * (2 * pos + wv)) / (2 * (total > 0 ? total : 1)));
+                q_new[i] = q < 0 ? 0 : (q > 3 ? 3 : q);
+                pos += wv;
+            }
+            for (int i = 0; i < n; ++i) quart[i] = q_new[i];
+            strip_h = solve_h();
+        }
     }
     LkTable t{};
     t.n = n;
@@ -147,7 +199,7 @@ int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
     for (int i = 0; i < n; ++i) {
         t.lv[i] = lv[i].a;
         t.lv[i].tiles_x = ofx_div_up(lv[i].a.w, G::OUT_W);
-        t.lv[i].strip_h = strip_h < lv[i].rows_out ? strip_h : lv[i].rows_out;
+        t.lv[i].strip_h = height(i, strip_h);
         t.first_block[i] = blocks;
         blocks += t.lv[i].tiles_x * ofx_div_up(lv[i].rows_out, t.lv[i].strip_h);
     }

@@ -136,36 +136,62 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         OFX_TRY(ofx_corner_args(C.level, C.levels, window, mode, C.d_uv, C.cols, C.d_status, &C.shard_rows[0][0], &S.corner[i], S.corner_lv + n_clv));
         S.corner[i].lv0 = n_clv;
         n_clv += C.levels;
-        if (C.build_patch) {
-            // the chain's patch pyramids are built by its own block first: one geometry for all the chains of a launch
-            OFX_REQUIRE(C.levels >= 2 && C.patch_w > 0 && C.patch_h > 0 && C.d_patch_src[0] && C.d_patch_src[1] && C.d_patch[0][1] && C.d_patch[1][1],
+        const bool reloc = C.levels >= 2 && C.d_patch_reloc[1] != nullptr;
+        S.corner[i].pair_status = C.d_pair_status;
+        if (C.build_patch || reloc) {
+            // the chain's patch pyramids are built (and, when a shift leaves them, rebuilt elsewhere) by its own block: one
+            // geometry for all the chains of a launch
+            OFX_REQUIRE(C.levels >= 2 && C.patch_w > 0 && C.patch_h > 0, "ofx_stream_launch: corner stage %d: incomplete patch description", i);
+            OFX_REQUIRE(!C.build_patch || (C.d_patch_src[0] && C.d_patch_src[1] && C.d_patch[0][1] && C.d_patch[1][1]),
                         "ofx_stream_launch: corner stage %d: incomplete patch description", i);
+            uint8_t *const *planes = C.build_patch ? C.d_patch[0] : C.d_patch_reloc; // (the set whose layout defines the offsets)
             PatchBuild pb{};
             pb.n = C.levels - 1;
-            pb.frame_stride = (int)(C.d_patch[1][1] - C.d_patch[0][1]);
+            pb.frame_stride = C.build_patch ? (int)(C.d_patch[1][1] - C.d_patch[0][1]) : 0;
             for (int k = 0; k < C.levels; ++k) {
                 pb.pw[k] = C.patch_w >> k;
                 pb.ph[k] = C.patch_h >> k;
                 pb.pitch[k] = k ? C.patch_pitch[k] : 0;
-                pb.off[k] = k ? (int)(C.d_patch[0][k] - C.d_patch[0][1]) : 0;
+                pb.off[k] = k ? (int)(planes[k] - planes[1]) : 0;
                 OFX_REQUIRE(pb.pw[k] > 0 && pb.ph[k] > 0, "ofx_stream_launch: the patch is too small for %d levels", C.levels);
                 if (k) {
-                    OFX_REQUIRE((C.patch_pitch[k] & 3) == 0 && C.patch_pitch[k] >= ((pb.pw[k] + 3) & ~3) && ((uintptr_t)C.d_patch[0][k] & 3) == 0 &&
-                                    C.d_patch[1][k] == C.d_patch[0][k] + pb.frame_stride,
+                    OFX_REQUIRE(planes[k] != nullptr && (C.patch_pitch[k] & 3) == 0 && C.patch_pitch[k] >= ((pb.pw[k] + 3) & ~3) && ((uintptr_t)planes[k] & 3) == 0,
                                 "ofx_stream_launch: corner stage %d: bad patch plane at level %d", i, k);
+                    OFX_REQUIRE(!C.build_patch || C.d_patch[1][k] == C.d_patch[0][k] + pb.frame_stride,
+                                "ofx_stream_launch: corner stage %d: bad patch plane at level %d", i, k);
+                    OFX_REQUIRE(!reloc || (C.d_patch_reloc[k] != nullptr && C.d_patch_reloc[k] - C.d_patch_reloc[1] == pb.off[k] && ((uintptr_t)C.d_patch_reloc[k] & 3) == 0),
+                                "ofx_stream_launch: corner stage %d: the relocated patch planes must be laid out like the patch planes (level %d)", i, k);
                     OFX_REQUIRE(((C.patch_w >> (k - 1)) & 1) == 0 && ((C.patch_h >> (k - 1)) & 1) == 0, "ofx_stream_launch: the patch must have even dimensions below its top level");
                 }
             }
-            for (int f = 0; f < 2; ++f)
-                OFX_REQUIRE((C.patch_src_pitch[f] & 3) == 0 && C.patch_src_pitch[f] >= C.patch_w && ((uintptr_t)C.d_patch_src[f] & 3) == 0,
-                            "ofx_stream_launch: corner stage %d: bad patch source", i);
+            if (C.build_patch)
+                for (int f = 0; f < 2; ++f)
+                    OFX_REQUIRE((C.patch_src_pitch[f] & 3) == 0 && C.patch_src_pitch[f] >= C.patch_w && ((uintptr_t)C.d_patch_src[f] & 3) == 0,
+                                "ofx_stream_launch: corner stage %d: bad patch source", i);
+            if (reloc) {
+                // the relocated build reads the whole next frame through level 0's descriptor, and the chain must be able to
+                // place the patch around any target: whole level-0 planes, a patch inside the frame, room for the window at
+                // the coarsest level (its stencils span radius + 3 pixels; one more for the plane's first column / row)
+                const ofx_geom &g0 = C.level[0].geom;
+                OFX_REQUIRE(g0.row0 == 0 && g0.rows == g0.h && (C.cols[0] == 0 || C.cols[0] >= g0.w),
+                            "ofx_stream_launch: corner stage %d: the repair needs level 0 to be the whole frames", i);
+                OFX_REQUIRE(C.patch_w <= g0.w && C.patch_h <= g0.h, "ofx_stream_launch: corner stage %d: the patch must lie inside the frame", i);
+                const int lc = C.levels - 1, need = (window >> 1) + 5;
+                OFX_REQUIRE((pb.pw[lc] >= need || pb.pw[lc] >= (g0.w >> lc)) && (pb.ph[lc] >= need || pb.ph[lc] >= (g0.h >> lc)),
+                            "ofx_stream_launch: corner stage %d: a %dx%d patch leaves %dx%d at the coarsest level, the repair needs %d", i, C.patch_w,
+                            C.patch_h, pb.pw[lc], pb.ph[lc], need);
+                S.corner[i].reloc = C.d_patch_reloc[1];
+            }
             if (S.patch.n == 0) S.patch = pb;
             else OFX_REQUIRE(memcmp(&S.patch, &pb, sizeof pb) == 0, "ofx_stream_launch: the corner stages of a launch must share one patch geometry");
-            S.patch_slot[i] = PatchBuildSlot{{C.d_patch_src[0], C.d_patch_src[1]}, {C.patch_src_pitch[0], C.patch_src_pitch[1]}, C.d_patch[0][1]};
-            ++n_build;
+            if (C.build_patch) {
+                S.patch_slot[i] = PatchBuildSlot{{C.d_patch_src[0], C.d_patch_src[1]}, {C.patch_src_pitch[0], C.patch_src_pitch[1]}, C.d_patch[0][1]};
+                ++n_build;
+            }
         }
     }
     OFX_REQUIRE(n_build == 0 || n_build == g->n_corner, "ofx_stream_launch: either every corner stage builds its patch or none does");
+    S.patch_build = n_build > 0 ? 1 : 0;
     S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;

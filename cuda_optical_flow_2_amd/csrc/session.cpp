@@ -57,7 +57,14 @@ struct ofx_session {
     int pw[OFX_MAX_LEVELS]{}, ph[OFX_MAX_LEVELS]{}, ppitch[OFX_MAX_LEVELS]{};
     // stream_two_stage: the patch planes the corner block of slot i builds for its pair (frame 0: previous, 1: next)
     uint8_t *pscr[kMaxBatch][2][OFX_MAX_LEVELS]{};
+    // the repair of a shift that leaves the patch (ofx_corner_stage.d_patch_reloc): per corner slot one more set of patch planes,
+    // for the next frame's pyramid rebuilt around the shifted corner.  Allocated where the whole frames stay at hand
+    // (borrow_frames) and the chain reads a patch (stream_two_stage, local_corner).
+    uint8_t *preloc[kMaxBatch][OFX_MAX_LEVELS]{};
+    bool repair = false;
+    int debug_extent = 0; // test hook (OFX_DEBUG_CORNER_EXTENT): the chain may only read this many level-0 columns / rows of its patch planes
     int *corner_status = nullptr;
+    int *pair_status = nullptr; // one word per shift-vector slot (pair p -> slot p mod 2B)
     const uint8_t *pframe[3] = {nullptr, nullptr, nullptr}; // borrow_frames, pair-at-a-time: the caller's frame behind img[i]'s level 0
     float *flow[OFX_MAX_LEVELS]{};       // where results are read from: flowset[0], or the newest pair's set in a two-frame stream
     float *flowset[kMaxBatch][OFX_MAX_LEVELS]{}; // stream pipeline: pair p's flow goes to set p mod stream_batch
@@ -215,8 +222,10 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         flow_stride.push_back(flow_bytes);
     }
     std::vector<size_t> off_patch[kSets];
-    std::vector<size_t> off_pscr; // (per level; slot i, frame f at + (2 i + f) * pscr_frame)
+    std::vector<size_t> off_pscr; // (per level; slot i, frame f at + (F i + f) * pscr_frame, F = frames per slot)
     size_t pscr_frame = 0;
+    const int n_slots = p->stream_batch >= 2 ? p->stream_batch : 1;
+    size_t patch_bytes[OFX_MAX_LEVELS] = {};
     if (p->local_corner || p->stream_two_stage) {
         const int step = 1 << (p->levels - 1);
         int side = p->patch_size > 0 ? p->patch_size : step * ((p->window >> 1) + 2 + 8);
@@ -227,21 +236,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             s->pw[k] = pw0 >> k;
             s->ph[k] = ph0 >> k;
             s->ppitch[k] = (int)align_up((size_t)s->pw[k], 64);
-            const size_t bytes = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
-            if (p->stream_two_stage) { // no patch pyramids per image set: the corner blocks build what they read
-                off_pscr.push_back(pscr_frame);
-                if (k >= 1) pscr_frame += bytes;
-                continue;
-            }
-            for (int t = 0; t < n_sets; ++t) {
-                off_patch[t].push_back(total);
-                total += bytes;
-            }
-        }
-        const size_t off_pscr_base = total;
-        if (p->stream_two_stage) {
-            total += pscr_frame * 2 * (size_t)(p->stream_batch >= 2 ? p->stream_batch : 1);
-            for (size_t &o : off_pscr) o += off_pscr_base;
+            patch_bytes[k] = align_up((size_t)s->ppitch[k] * (size_t)s->ph[k] + 64, kAlign);
         }
         const int need = (p->window >> 1) + 2;
         const int lc = p->levels - 1;
@@ -251,9 +246,36 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
             delete s;
             return OFX_E_INVALID;
         }
+        // With the frames borrowed the whole next frame is at hand when the chain runs: a shift that leaves the patch is repaired
+        // (ofx_corner_stage.d_patch_reloc) -- provided the patch leaves room at the coarsest level to be placed around any
+        // target (radius + 3 pixels of stencils + the plane's first column / row); a smaller patch (patch_size) keeps the
+        // status bit.
+        const int need_r = (p->window >> 1) + 5;
+        s->repair = p->borrow_frames && p->levels >= 3 && (s->pw[lc] >= need_r || s->pw[lc] >= s->w[lc]) && (s->ph[lc] >= need_r || s->ph[lc] >= s->h[lc]);
     }
-    const size_t off_status = total;
-    total += kAlign;
+    if (s->repair) {
+        // Test hook: pretend the top-left patch planes are only this many level-0 pixels wide and high (never less than the
+        // corner itself), so that ordinary frames drive the chain into the relocated planes; the results must not change.
+        const char *e = getenv("OFX_DEBUG_CORNER_EXTENT");
+        s->debug_extent = e ? atoi(e) : 0;
+    }
+    const int frames_per_slot = (p->stream_two_stage ? 2 : 0) + (s->repair ? 1 : 0);
+    if (p->local_corner || p->stream_two_stage) {
+        for (int k = 0; k < p->levels; ++k) {
+            off_pscr.push_back(pscr_frame);
+            if (k >= 1) pscr_frame += patch_bytes[k];
+            if (p->stream_two_stage) continue; // no patch pyramids per image set: the corner blocks build what they read
+            for (int t = 0; t < n_sets; ++t) {
+                off_patch[t].push_back(total);
+                total += patch_bytes[k];
+            }
+        }
+        const size_t off_pscr_base = total;
+        total += pscr_frame * (size_t)frames_per_slot * (size_t)n_slots;
+        for (size_t &o : off_pscr) o += off_pscr_base;
+    }
+    const size_t off_status = total; // the sticky word, then one word per shift-vector slot
+    total += align_up(sizeof(int) * (size_t)(1 + kUvSlots), kAlign);
     const size_t off_uv = total;
     total += align_up((size_t)OFX_MAX_LEVELS * 2 * sizeof(float) * kUvSlots, kAlign);
     const size_t off_staging = total; // one 3-channel frame for ofx_session_set_frame_host_3ch (unsharded sessions only)
@@ -286,11 +308,17 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     if (p->local_corner && !p->stream_two_stage)
         for (int k = 0; k < p->levels; ++k)
             for (int t = 0; t < n_sets; ++t) s->pimg[t][k] = base + off_patch[t][k];
-    if (p->stream_two_stage)
-        for (int i = 0; i < (p->stream_batch >= 2 ? p->stream_batch : 1); ++i)
-            for (int f = 0; f < 2; ++f)
-                for (int k = 1; k < p->levels; ++k) s->pscr[i][f][k] = base + off_pscr[k] + (size_t)(2 * i + f) * pscr_frame;
+    for (int i = 0; i < n_slots && frames_per_slot > 0; ++i)
+        for (int k = 1; k < p->levels; ++k) {
+            uint8_t *slot = base + off_pscr[k] + (size_t)(frames_per_slot * i) * pscr_frame;
+            if (p->stream_two_stage) {
+                s->pscr[i][0][k] = slot;
+                s->pscr[i][1][k] = slot + pscr_frame;
+            }
+            if (s->repair) s->preloc[i][k] = slot + (size_t)(frames_per_slot - 1) * pscr_frame;
+        }
     s->corner_status = reinterpret_cast<int *>(base + off_status);
+    s->pair_status = s->corner_status + 1;
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = p->sharded ? nullptr : base + off_staging;
     repoint(s);
@@ -761,6 +789,17 @@ extern "C" int ofx_session_corner_status(ofx_session *s, int *h_status, void *st
     return OFX_OK;
 }
 
+extern "C" int ofx_session_pair_status(ofx_session *s, int pair, int *h_status, void *stream)
+{
+    OFX_REQUIRE(s && h_status, "ofx_session_pair_status: null argument");
+    const int slots = 2 * (s->p.stream_batch >= 2 ? s->p.stream_batch : 1);
+    OFX_REQUIRE(pair >= 1, "ofx_session_pair_status: pairs are counted from 1 (frame 0 -> frame 1)");
+    hipStream_t st = ofx_stream(stream);
+    OFX_HIP(hipMemcpyAsync(h_status, s->pair_status + (pair % slots), sizeof(int), hipMemcpyDeviceToHost, st));
+    OFX_HIP(hipStreamSynchronize(st));
+    return OFX_OK;
+}
+
 // ---- stream pipeline: one launch per tick of B frames ----------------------------------------------------------------
 // Frame f (0-based) belongs to tick f / B (B = stream_batch: 1, 2 or 4).  Pair p is (frame p-1 -> frame p).  The tick
 // whose first frame is f0 runs, side by side in one grid,
@@ -799,6 +838,13 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     auto pitch_of = [&](long frame, int k, bool patch) {
         if (k == 0 && s->p.borrow_frames) return s->bpitch[set_of(frame)];
         return patch ? s->ppitch[k] : s->pitch[k];
+    };
+    // columns / rows of level k's patch planes the corner chain may read (all of them, unless the test hook narrows them)
+    auto chain_extent = [&](int k, int full) {
+        if (s->debug_extent <= 0 || k == 0) return full;
+        const int need = (s->p.window >> 1) + 2, lim = s->debug_extent >> k;
+        const int e = lim > need ? lim : need;
+        return e < full ? e : full;
     };
     // the stages struct is several KB: keep it off the stack of callers with small stacks
     static thread_local ofx_stream_stages g;
@@ -859,12 +905,16 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                 C.patch_pitch[k] = s->ppitch[k];
                 C.d_patch[0][k] = s->pscr[slot_i][0][k];
                 C.d_patch[1][k] = s->pscr[slot_i][1][k];
+                C.d_patch_reloc[k] = s->repair ? s->preloc[slot_i][k] : nullptr;
                 const uint8_t *pp = k ? s->pscr[slot_i][0][k] : C.d_patch_src[0], *pn = k ? s->pscr[slot_i][1][k] : C.d_patch_src[1];
-                ofx_geom pg{s->w[k], s->h[k], k ? s->ppitch[k] : C.patch_src_pitch[1], 0, s->ph[k], 0, s->ph[k]};
+                // level 0 is the frames themselves, whole (every rank of a sharded stream is handed whole frames)
+                ofx_geom pg{s->w[k], s->h[k], k ? s->ppitch[k] : C.patch_src_pitch[1], 0, k ? chain_extent(k, s->ph[k]) : s->h[0], 0,
+                            k ? chain_extent(k, s->ph[k]) : s->h[0]};
                 C.level[k] = ofx_lk_desc{pp, pn, pg, nullptr, 0, nullptr, 0, s->p.min_det};
-                C.cols[k] = s->pw[k];
+                C.cols[k] = k ? chain_extent(k, s->pw[k]) : 0;
             }
             C.d_status = s->corner_status;
+            C.d_pair_status = s->pair_status + (pc % slots);
             if (s->p.sharded) shard_reach(s, C.shard_rows);
             continue;
         }
@@ -872,18 +922,30 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         for (int k = 0; k < L; ++k) {
             // (both frames of a pair come through the same API with the same pitch; a borrowed level 0 uses the caller's)
             if (s->p.local_corner) {
-                ofx_geom pg{s->w[k], s->h[k], pitch_of(pc, k, true), 0, s->ph[k], 0, s->ph[k]};
+                // (a borrowed level 0 is the whole frame: the chain may read all of it, and the repair rebuilds from it)
+                const bool whole0 = k == 0 && s->p.borrow_frames;
+                const int rows_k = whole0 ? s->h[0] : chain_extent(k, s->ph[k]);
+                ofx_geom pg{s->w[k], s->h[k], pitch_of(pc, k, true), 0, rows_k, 0, rows_k};
                 C.level[k] = ofx_lk_desc{patch_of(pc - 1, k), patch_of(pc, k), pg, nullptr, 0, nullptr, 0, s->p.min_det};
-                C.cols[k] = s->pw[k];
+                C.cols[k] = whole0 ? 0 : chain_extent(k, s->pw[k]);
             } else {
                 ofx_geom cg = level_geom(s, k, 0, s->h[k]);
                 cg.pitch = pitch_of(pc, k, false);
                 C.level[k] = ofx_lk_desc{plane_of(pc - 1, k), plane_of(pc, k), cg, nullptr, 0, nullptr, 0, s->p.min_det};
             }
         }
+        C.d_pair_status = s->pair_status + (pc % slots);
         if (s->p.local_corner) {
             C.d_status = s->corner_status;
             if (s->p.sharded) shard_reach(s, C.shard_rows);
+            if (s->repair) {
+                C.patch_w = s->pw[0];
+                C.patch_h = s->ph[0];
+                for (int k = 0; k < L; ++k) {
+                    C.patch_pitch[k] = s->ppitch[k];
+                    C.d_patch_reloc[k] = s->preloc[slot_i][k];
+                }
+            }
         }
     }
     long newest = -1;

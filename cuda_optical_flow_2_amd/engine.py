@@ -80,8 +80,13 @@ class Session:
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
                  shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False,
-                 min_det: float = 0.0, two_stage: bool = False):
+                 min_det: float = 0.0, two_stage: bool = False, strict: bool = True):
+        """strict: stream_drain() raises OfxError when the pipeline has drained and the session's status word is not 0 -- a pair
+        whose result is NOT the reference's (a corner shift that left the patch of a session that cannot repair it, a shift or
+        warp beyond a shard's halo; include/ofx.h, ofx_session_corner_status).  strict=False: poll corner_status() yourself."""
         self.L = _lib.load()
+        self.strict = bool(strict)
+        self._status = 0
         self.width, self.height, self.levels, self.window, self.mode = width, height, levels, window, mode
         p = Params()
         p.width, p.height, p.levels, p.window, p.mode, p.device = width, height, levels, window, MODES[mode], device
@@ -184,6 +189,16 @@ class Session:
         """local_corner sessions: OR of the "shift left the patch at level k" bits since the last call (0 = all exact)."""
         st = C.c_int(0)
         check(self.L.ofx_session_corner_status(self._h, C.byref(st), _stream_ptr(stream)), "corner_status")
+        word, self._status = int(st.value) | self._status, 0
+        return word
+
+    STATUS_REPAIRED = 1 << 24   # OFX_STATUS_REPAIRED
+
+    def pair_status(self, pair: int, stream=None) -> int:
+        """Status word of ONE pair of the stream pipeline (ofx_session_pair_status): the error bits that pair raised, plus
+        STATUS_REPAIRED when its shifted corner left the top-left patch and was read through a relocated one (exact all the same)."""
+        st = C.c_int(0)
+        check(self.L.ofx_session_pair_status(self._h, pair, C.byref(st), _stream_ptr(stream)), "pair_status")
         return int(st.value)
 
     def stream_begin(self):
@@ -209,6 +224,17 @@ class Session:
     def stream_drain(self, stream=None) -> int:
         done = C.c_int(-1)
         check(self.L.ofx_session_stream_drain(self._h, _stream_ptr(stream), C.byref(done)), "stream_drain")
+        if done.value == -2 and self.strict:
+            # the pipeline is empty: every pair it produced must have been the reference's (one synchronising read per drained
+            # stream, not per frame).  The word is kept for corner_status() when the caller wants to look at it.
+            st = C.c_int(0)
+            check(self.L.ofx_session_corner_status(self._h, C.byref(st), _stream_ptr(stream)), "corner_status")
+            self._status |= int(st.value)
+            if self._status:
+                word, self._status = self._status, 0
+                raise _lib.OfxError(f"stream pipeline: status word {word:#x} -- bit k: level k's corner shift left the patch and could not be "
+                                    "repaired; bit 8+k / 16+k: a shift / warp reached beyond this shard's halo: those pairs are not the "
+                                    "reference's result (include/ofx.h, ofx_session_corner_status)")
         return done.value
 
     def push_frame_host(self, gray1: np.ndarray, stream=None):

@@ -171,7 +171,20 @@ typedef struct ofx_corner_stage {
     int patch_src_pitch[2];
     uint8_t *d_patch[2][OFX_MAX_LEVELS];
     int patch_pitch[OFX_MAX_LEVELS];
+    /* REPAIR of a shift that leaves the patch (cpu::shift_back_pyramid defines the shift for every input,
+     * OptFlowCPU.cpp:255-273: a flat or nearly singular corner sends the next level's shifted corner anywhere in the image).
+     * d_patch_reloc[1 .. levels-1] != NULL: a third set of patch planes (same sizes and pitches as d_patch[f]); when level k
+     * needs a pixel of the next frame's pyramid that the top-left patch does not hold, the stage's block rebuilds that small
+     * pyramid AROUND the shifted corner from the whole next frame and runs the level again on it -- no status bit, no host
+     * round trip, the reference's result.  Needs level[0] to describe the WHOLE frames (geom.rows = h, cols[0] = 0 or w) and
+     * patch_w / patch_h / patch_pitch to be set (with or without build_patch).  NULL: bit k of the status words is raised
+     * instead, as before.
+     * d_pair_status (may be NULL): THIS pair's status word is WRITTEN there when the chain ends: the bits raised in
+     * *d_status by this pair, plus OFX_STATUS_REPAIRED when a relocated patch was used (the pair is exact all the same). */
+    uint8_t *d_patch_reloc[OFX_MAX_LEVELS];
+    int *d_pair_status;
 } ofx_corner_stage;
+#define OFX_STATUS_REPAIRED (1 << 24)
 typedef struct ofx_stream_stages {
     ofx_pyramid_stage pyr[OFX_STREAM_MAX_BATCH];
     int n_pyr;
@@ -341,8 +354,9 @@ typedef struct ofx_params {
      * row 0.  Every frame handed to the session is the whole frame, so the patch is always at hand; with it a rank
      * needs nothing from any other rank and can run the one-launch-per-frame stream pipeline
      * (ofx_session_stream_*).  patch_size: level-0 side of the square patch, 0 = automatic
-     * (2^(levels-1) * (window/2 + 2 + 8), at least 256, clipped to the frame).  The shift is exact while it stays inside
-     * the patch; ofx_session_corner_status reports when it did not. */
+     * (2^(levels-1) * (window/2 + 2 + 8), at least 256, clipped to the frame).  With borrow_frames the shift is exact for
+     * every input (a shifted corner that leaves the patch is read through a relocated one, ofx_corner_stage.d_patch_reloc);
+     * with copied frames it is exact while it stays inside the patch and ofx_session_corner_status reports when it did not. */
     int local_corner;
     int patch_size;
     /* frames per tick of the stream pipeline: 0 or 1 = one launch per frame, 2 .. 16 = one launch per that many frames
@@ -372,9 +386,9 @@ typedef struct ofx_params {
      * (ofx_corner_stage.build_patch) instead of waiting a tick for the pyramid stage.  A pair's flow is complete one tick
      * earlier, the pipeline holds 2B + 2 image sets instead of 3B + 2 and a borrowed frame f is read until the launch
      * enqueued by the submit of frame f + 2B (ring of >= 2B + 1 buffers) -- which is what lets eight 4K frames per launch
-     * stay inside the Infinity Cache.  Needs borrow_frames.  Like local_corner, the shift vectors are exact while the
-     * shifted corner stays inside the patch (256 level-0 pixels or patch_size); ofx_session_corner_status reports (bit k)
-     * the pairs for which it did not. */
+     * stay inside the Infinity Cache.  Needs borrow_frames.  The shift vectors are exact for EVERY input: a shifted corner that
+     * leaves the patch (256 level-0 pixels or patch_size) is read through a patch pyramid the corner block rebuilds around it
+     * (ofx_corner_stage.d_patch_reloc; ofx_session_pair_status says for which pairs that happened). */
     int stream_two_stage;
     int reserved[1];
 } ofx_params;
@@ -385,6 +399,12 @@ int ofx_session_create(const ofx_params *p, ofx_session **out);
  * margin rows of the plan) and bit 16 + k = "a refinement iteration's warp at level k reached beyond the halo" (iters > 1);
  * 0 = every pair so far is exactly the unsharded result.  Synchronises `stream`. */
 int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream);
+/* The same word for ONE pair of the stream pipeline (frames counted from 0, pair p = frame p-1 -> frame p), while it is one of
+ * the newest 2 * stream_batch pairs whose corner stage has run: the bits that pair raised, plus OFX_STATUS_REPAIRED when its
+ * shifted corner left the top-left patch and was read through a relocated one (informational: the flow is the reference's).
+ * With the repair in place (stream_two_stage, or local_corner with borrow_frames) bit k can no longer occur; bits 8 + k and
+ * 16 + k (a shard's halo) stay errors.  Synchronises `stream`; does not clear anything. */
+int ofx_session_pair_status(ofx_session *s, int pair, int *h_status, void *stream);
 int ofx_session_destroy(ofx_session *s);
 /* Load the NEXT frame's level 0 (1ch, tightly packed w bytes per row, full frame) from host / device memory. */
 int ofx_session_set_frame_host(ofx_session *s, const uint8_t *h_gray1, void *stream);

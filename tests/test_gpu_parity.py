@@ -228,7 +228,7 @@ def test_sharded_session_reports_a_shift_beyond_its_halo(eng):
     v1 = float(plain.uv(1).cpu()[1])
     plain.close()
     assert abs(v1) > 40, "this pair is expected to have a wild level-1 shift"
-    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R), local_corner=True) for r in range(R)]
+    ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R), local_corner=True, strict=False) for r in range(R)]
     for s in ranks:
         s.stream_begin()
         for f in frames:
@@ -617,7 +617,7 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     for d in (10, 20, 40, 80):
         a = np.clip(np.floor(base), 0, 255).astype(np.uint8)
         b = np.clip(np.floor(base + d), 0, 255).astype(np.uint8)
-        s = eng.Session(w, h, L, win, "lk_float", local_corner=True, patch_size=patch)
+        s = eng.Session(w, h, L, win, "lk_float", local_corner=True, patch_size=patch, strict=False)   # (copied frames: no repair)
         s.stream_begin()
         expected = 0
         for i, f in enumerate([a, b, a, b]):
@@ -647,6 +647,124 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
         seen_miss = seen_miss or got != 0
         s.close()
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
+
+
+def _plain_sequence(eng, frames, w, h, L, win, mode="lk_float"):
+    """flows of every pair of `frames` through the plain pair-at-a-time session (the sequence the oracle tests pin)"""
+    import torch
+
+    plain = eng.Session(w, h, L, win, mode)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, len(frames)):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        torch.cuda.synchronize()
+        want[i] = [plain.flow_host(k) for k in range(L)]
+        plain.swap()
+    plain.close()
+    return want
+
+
+def _stream_all_pairs(s, frames, L, B):
+    """every pair of `frames` through the stream pipeline of session s; returns {pair: [flow per level]} (host copies)"""
+    import torch
+
+    got, seen = {}, 0
+
+    def snap(done):
+        nonlocal seen
+        if done >= 1:
+            for p in range(max(seen + 1, done - B + 1), done + 1):
+                got[p] = [s.flow_of(p, k)[0].cpu().numpy() for k in range(L)]
+            seen = done
+
+    s.stream_begin()
+    for f in frames:
+        snap(s.stream_submit(f))
+    while True:
+        done = s.stream_drain()
+        if done == -2:
+            break
+        snap(done)
+    torch.cuda.synchronize()
+    return got
+
+
+@pytest.mark.parametrize("kind", ["two_stage", "local_corner"])
+@pytest.mark.parametrize("batch", [1, 2, 4])
+def test_corner_shift_that_leaves_the_patch_is_repaired(eng, oracle, kind, batch, monkeypatch):
+    """cpu::shift_back_pyramid defines the shift for EVERY input (OptFlowCPU.cpp:255-273).  The fast stream paths form the shift
+    vectors from a small top-left patch of each frame; when a shifted corner leaves it, the corner block rebuilds the next
+    frame's patch pyramid around the target (ofx_corner_stage.d_patch_reloc, sessions on borrowed frames) and the pair is the
+    reference's all the same.  Pixel 0's flow saturates at a few pixels per level on anything but adversarial input (the
+    zero border dominates its gradients), always inside a patch of the automatic size, so the test narrows what the chain may
+    read of its patch planes to 16 level-0 pixels (OFX_DEBUG_CORNER_EXTENT, a hook for this test) and feeds pairs that
+    darken over a shallow ramp: shifts of 4 / 13 / 30 pixels at levels 2 / 1 / 0.  Every pair must carry the bits of the plain
+    sequence -- whose first pair is tied to the oracle here -- with status word 0, and the pairs' own words must say that
+    relocated planes were used."""
+    import torch
+
+    w, h, L, win = 1024, 768, 4, 5
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    tex = synth.smooth_pair(w, h, 0, 0, seed=3)[1].astype(np.float64)
+    host = []
+    for g, d in [(0.25, 50), (0.25, 0), (0.5, 25), (0.5, 0), (0.125, 12), (0.125, 0), (1.0, 50), (1.0, 3), (0.25, 25)]:
+        base = xx * g + yy * g * 0.7 + 0.15 * tex
+        host.append(np.clip(np.floor(base + d), 0, 255).astype(np.uint8))   # (darkening pairs: positive shifts, into the image)
+    frames = [torch.from_numpy(f).cuda() for f in host]
+    want = _plain_sequence(eng, frames, w, h, L, win)
+    fl, _, _ = oracle.flow_pair(synth.to_3ch(host[0]), synth.to_3ch(host[1]), L, win, "lk_float", exact_sums=True)
+    for k in range(L):
+        assert_same(want[1][k], fl[k], f"plain sequence vs oracle, level {k}")
+    # the subject of the test: the reference's shift of level 1 (from pixel 0 of the coarser flows) is beyond the narrowed planes
+    u1 = sum(np.float32(1 << (j - 1)) * fl[j][0, 0, 0] for j in range(L - 1, 1, -1))
+    assert u1 > 8, f"level-1 shift {u1}: the frames no longer push the corner out of the narrowed patch"
+    monkeypatch.setenv("OFX_DEBUG_CORNER_EXTENT", "16")
+    if kind == "two_stage":
+        s = eng.Session(w, h, L, win, "lk_float", stream_batch=batch, borrow_frames=True, two_stage=True)
+    else:
+        s = eng.Session(w, h, L, win, "lk_float", stream_batch=batch, borrow_frames=True, local_corner=True)
+    monkeypatch.delenv("OFX_DEBUG_CORNER_EXTENT")
+    got = _stream_all_pairs(s, frames, L, batch)
+    assert sorted(got) == list(range(1, len(frames)))
+    for p in got:
+        for k in range(L):
+            assert_same(got[p][k], want[p][k], f"{kind} batch {batch} pair {p} level {k}")
+    assert s.corner_status() == 0
+    words = [s.pair_status(p) for p in range(max(1, len(frames) - 2 * batch), len(frames))]
+    assert all((wd & 0xFFFFFF) == 0 for wd in words), words
+    assert any(wd & s.STATUS_REPAIRED for wd in words), f"no pair used the relocated planes: {words}"
+    s.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_near_singular_corner_through_two_stage_equals_plain_sequence(eng, seed):
+    """A corner with almost no texture makes pixel 0's determinant tiny and its flow arbitrary -- huge, negative, Inf or NaN --
+    so the shifts of the finer levels land anywhere.  Whatever they are, the two-stage stream pipeline must reproduce the plain
+    sequence bit for bit with status word 0 (noise frames whose top-left region is flat up to +-1 LSB, several seeds)."""
+    import torch
+
+    w, h, L, win = 1280, 768, 5, 9
+    rng = np.random.default_rng(seed)
+    host = []
+    for i in range(7):
+        f = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        flat = rng.integers(40, 200)
+        n = 48 + 16 * (i % 3)
+        f[:n, :n] = flat + rng.integers(-1, 2, (n, n))
+        if i % 2:
+            f[: n // 2, : n // 2] = flat   # exactly flat: singular (NaN / Inf flows, no shift)
+        host.append(f)
+    frames = [torch.from_numpy(f).cuda() for f in host]
+    want = _plain_sequence(eng, frames, w, h, L, win)
+    for batch in (1, 4):
+        s = eng.Session(w, h, L, win, "lk_float", stream_batch=batch, borrow_frames=True, two_stage=True)
+        got = _stream_all_pairs(s, frames, L, batch)
+        for p in got:
+            for k in range(L):
+                assert_same(got[p][k], want[p][k], f"seed {seed} batch {batch} pair {p} level {k}")
+        assert s.corner_status() == 0
+        s.close()
 
 
 @pytest.mark.parametrize("batch,borrow", [(2, False), (4, False), (8, False), (16, False), (1, True), (4, True), (8, True), (16, True),
@@ -1170,9 +1288,9 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
         want[i] = [plain.flow_host(k) for k in range(L)]
         plain.swap()
     plain.close()
-    def run(warp_margin):
+    def run(warp_margin, strict=True):
         ranks = [eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, r, R, iters=iters, warp_margin=warp_margin),
-                             local_corner=True, stream_batch=B, iters=iters) for r in range(R)]
+                             local_corner=True, stream_batch=B, iters=iters, strict=strict) for r in range(R)]
         return ranks
 
     ranks = run(wm)
@@ -1201,7 +1319,7 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
         assert s.corner_status() == 0
         s.close()
     if wm > 8:   # the same with the default slack: whatever differs is flagged
-        ranks = run(8)
+        ranks = run(8, strict=False)
         for s in ranks:
             s.stream_begin()
             for f in frames:

@@ -53,7 +53,7 @@ def run(n_cfg: int, seed: int, verbose: bool = True) -> int:
           if R == 1:
               ranks = [eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=borrow, two_stage=two_stage)]
           else:
-              ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B,
+              ranks = [eng.Session(w, h, L, win, mode, shard=ShardPlan(w, h, L, win, r, R), local_corner=True, stream_batch=B, strict=False,
                                    borrow_frames=borrow, two_stage=two_stage) for r in range(R)]
           got, seen = {}, 0
           for s in ranks:

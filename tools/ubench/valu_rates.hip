@@ -15,6 +15,9 @@ template <int OP>
 __global__ __launch_bounds__(256) void k(int *out, int n, int seed)
 {
     int a[8], b = seed | 1, c = seed + 3;
+    unsigned long long m64 = 0x5555555555555555ull + (unsigned)seed;
+    asm volatile("" : "+s"(m64));
+    if constexpr (OP == 27) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(b), "v"(c) : "vcc");
     double d[8];
     float f[8];
 #pragma unroll
@@ -56,6 +59,18 @@ __global__ __launch_bounds__(256) void k(int *out, int n, int seed)
                 if constexpr (OP == 29) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(b));
                 if constexpr (OP == 30) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]));
                 if constexpr (OP == 31) asm volatile("v_sad_u16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if constexpr (OP == 32) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(m64));
+                if constexpr (OP == 33) asm volatile("v_or3_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if constexpr (OP == 34) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+                if constexpr (OP == 35) asm volatile("v_cmp_lt_i32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");
+                if constexpr (OP == 36) { int sr; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(sr) : "v"(a[i])); }
+                if constexpr (OP == 37) asm volatile("v_sub_u32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(b));
+                if constexpr (OP == 38) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(a[i]));
+                if constexpr (OP == 39) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+                if constexpr (OP == 40) asm volatile("v_cvt_f32_u32 %0, %1" : "=v"(f[i]) : "v"(a[i]));
+                if constexpr (OP == 41) asm volatile("v_div_fixup_f64 %0, %0, %1, 1.0" : "+v"(d[i]) : "v"(d[(i + 1) & 7]));
+                if constexpr (OP == 42) asm volatile("v_mov_b32 %0, %1" : "=v"(a[i]) : "v"(b));
+                if constexpr (OP == 43) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[i]));
             }
         }
     }
@@ -95,12 +110,15 @@ int main()
                            "v_fma_f32", "v_pk_add_u16", "v_pk_mad_u16", "v_dot2_i32_i16", "v_fma_f64", "v_mul_f64", "v_add_f64",
                            "v_cvt_f64_i32", "v_lshl_add_u32", "v_add3_u32", "v_perm_b32", "v_mul_i24_sdwa", "v_rcp_f64", "v_cvt_f32_i32",
                            "v_cvt_f64_f32", "v_cvt_f32_f64", "v_pk_fma_f32", "v_mad_u64_u32", "v_mul_lo_u32", "v_pk_mul_lo_u16", "v_cndmask",
-                           "v_add_u32_dpp", "v_pk_sub_i16", "v_mov_dpp row_shr", "v_sad_u16"};
+                           "v_add_u32_dpp", "v_pk_sub_i16", "v_mov_dpp row_shr", "v_sad_u16", "v_cndmask_e64 sgpr", "v_or3_b32",
+                           "v_max3_i32", "v_cmp_lt_i32 vcc", "v_readfirstlane", "v_sub_u32_dpp shl", "v_lshlrev_b32", "v_sub_u32", "v_cvt_f32_u32",
+                           "v_div_fixup_f64", "v_mov_b32", "v_rcp_f32"};
     const int n = 4000;
     printf("%-22s %10s %10s %10s   (ns per wave-instr per SIMD; x2.4 = cycles @2.4GHz)\n", "op", "W=1", "W=2", "W=4");
 #define ROW(OP) { double a = run<OP>(1, n), b = run<OP>(2, n), c = run<OP>(4, n); \
     printf("%-22s %10.3f %10.3f %10.3f   cyc@2.4: %5.2f %5.2f %5.2f\n", names[OP], a*1e9, b*1e9, c*1e9, a*2.4e9, b*2.4e9, c*2.4e9); }
     ROW(0) ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6) ROW(7) ROW(8) ROW(9) ROW(10) ROW(11) ROW(12) ROW(13) ROW(14) ROW(15) ROW(16)
     ROW(17) ROW(18) ROW(19) ROW(20) ROW(21) ROW(22) ROW(23) ROW(24) ROW(25) ROW(26) ROW(27) ROW(28) ROW(29) ROW(30) ROW(31)
+    ROW(32) ROW(33) ROW(34) ROW(35) ROW(36) ROW(37) ROW(38) ROW(39) ROW(40) ROW(41) ROW(42) ROW(43)
     return 0;
 }
