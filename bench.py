@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- Mpix/s of dense pyramidal LK flow on MI355X (BASELINE.json metric), one JSON line on rank 0.
 
-A step = one frame pair: take the new frame's level 0 (already resident in HBM), build its pyramid, run every
-pyramid level coarse->fine against the previous frame's pyramid, swap.  That is main.cu:246-272 of the reference.
+A step = one pass of the hot path over one batch of input: take the new frames' level 0 (already resident in HBM), build
+their pyramids, run every pyramid level coarse->fine against the previous frames' pyramids.  That is main.cu:246-272 of the
+reference.  The stream path hands the session a tick of frames per step (one launch), the pair-at-a-time paths one pair.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k|vga] [--mode lk_float|compat_cpu]
 
@@ -11,11 +12,13 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame pair
 
 The line carries, besides the contract's fields: `roofline` (dominant kernel, HIP events on its stream), `self_check`
 (flows of the timed session compared with an independent plain session after the timed region; the run fails when they
-differ), `extra` (further legs measured in the same process: the literal BASELINE configuration with its iterations,
-cache-cold inputs, the bug-for-bug compat_cpu mode, the host-pointer gpu:: API with PCIe, the frame front end, ...) and
-`cpu_baseline` (the reference's own CPU code on this host: one thread and all cores).
+differ), `extra` (further legs measured in the same process, one function each below: every BASELINE configuration as it is
+written -- with its iterations -- and with iters = 1, a uniform-random pair, cache-cold inputs, the bug-for-bug compat_cpu
+mode, the pair-at-a-time path, the host-pointer gpu:: API with PCIe, the frame front end, ...) and `cpu_baseline` (the
+reference's own CPU code on this host: one thread with its stage split, and all cores).
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -40,7 +43,10 @@ LK_BYTES_PER_PX = 10       # fused level kernel: 2 u8 read + one (u,v) float pai
 LK_ACC_BYTES_PER_PX = 18   # refinement launch: the same + the 8-byte flow read back
 WARP_BYTES_PER_PX = 10     # bilinear warp: 1 u8 + 8 flow read, 1 u8 written
 PYR_BYTES_PER_DST_PX = 5   # downsample: 4 u8 read + 1 written per destination pixel
+MAX_LK_ITEMS = 80          # OFX_MAX_LK_ITEMS: (pair, level) items one launch carries
 
+
+# ---- sizes and bytes ------------------------------------------------------------------------------------------------------
 
 def level_px(w, h, levels, rows=None):
     """pixels of every level (rows: per-level (y0, y1) of a shard's own rows)"""
@@ -51,6 +57,33 @@ def pair_bytes(w, h, levels, rows=None, pyramid=True):
     px = level_px(w, h, levels, rows)
     return LK_BYTES_PER_PX * sum(px) + (PYR_BYTES_PER_DST_PX * sum(px[1:]) if pyramid else 0)
 
+
+def iters_pair_bytes(w, h, levels, iters, rows=None):
+    """a pair with refinement iterations: 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid"""
+    px = level_px(w, h, levels, rows)
+    return (LK_BYTES_PER_PX + (iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
+
+
+def roofline_block(nbytes, us, **more):
+    gbs = nbytes / (us * 1e-6) / 1e9 if us else 0.0
+    out = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    out.update(more)
+    return out
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel sources of the library: what profiles/traffic_latest.json was measured for"""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "cuda_optical_flow_2_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ofx.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# ---- CPU baseline (the only place besides tests/ and smoke() that may use oracle/) ---------------------------------------
 
 def host_cpu():
     """model name, online cores of this process (lscpu / /proc/cpuinfo)"""
@@ -74,6 +107,34 @@ def host_cpu():
     except (OSError, ValueError):
         pass
     return model, cores[:64]
+
+
+def cpu_stage_split(orc, use_ref, p3, n3, window):
+    """One level (level 0 of the sample, as the top level of a one-level pyramid: no shift) of cpu::calc_optical_flow split
+    into its stages, as SURVEY 8d / BASELINE.md 3 ask: 4 x conv_3ch_to_1ch, 5 x srm_1ch, the rest (sub, solve, 10 malloc / free)."""
+    import numpy as np
+
+    eng = orc.Reference() if use_ref else orc.Oracle()
+    h, w, _ = p3.shape
+    mask = eng.Dx_3x3
+
+    def clock(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return r, (time.perf_counter() - t0) * 1e3
+
+    ix, t_conv = clock(lambda: eng.conv_3ch_to_1ch(p3, mask))
+    _, t_srm = clock(lambda: eng.srm_1ch(ix, ix, window, window))
+    flow = [np.zeros((h, w, 2), np.float32)]
+    if use_ref:
+        _, t_level = clock(lambda: eng.calc_optical_flow(p3, n3, flow, 0, 1))
+    else:
+        _, t_level = clock(lambda: eng.calc_optical_flow_cpu(p3, n3, flow, 0, 1, window))
+    return {"level": f"{w}x{h} level 0 alone (one-level pyramid: no shift), window {window}x{window}",
+            "conv_3ch_to_1ch_ms": round(t_conv, 1), "conv_calls": 4, "srm_1ch_ms": round(t_srm, 1), "srm_calls": 5,
+            "whole_level_ms": round(t_level, 1), "solve_sub_alloc_ms": round(max(0.0, t_level - 4 * t_conv - 5 * t_srm), 1),
+            "share": {"conv": round(4 * t_conv / t_level, 3), "window_sums": round(5 * t_srm / t_level, 3),
+                      "solve_and_rest": round(max(0.0, 1 - (4 * t_conv + 5 * t_srm) / t_level), 3)}}
 
 
 def cpu_baseline(workload, w, h, levels, window, all_cores=True):
@@ -109,6 +170,10 @@ def cpu_baseline(workload, w, h, levels, window, all_cores=True):
         "cpu_model": model, "host_cores": len(cores),
         "sample": f"{reps} pair(s) {sw}x{sh}, {levels} levels, window {window}x{window}, both pyramids + all levels, {what}, {dt:.1f} s",
     }
+    try:
+        out["stages"] = cpu_stage_split(orc, use_ref, p3, n3, window)
+    except Exception as e:   # (the split is a report, never a reason to lose the line)
+        out["stages"] = {"error": str(e)}
     if all_cores and len(cores) > 1:
         procs = []
         worker = os.path.join(ROOT, "oracle", "cpu_worker.py")
@@ -134,7 +199,9 @@ def cpu_baseline(workload, w, h, levels, window, all_cores=True):
     return out
 
 
-def main():
+# ---- arguments and the plan of the stream path ----------------------------------------------------------------------------
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -150,6 +217,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the additional legs reported under extra (profiling runs: only the timed configuration's launches)")
+    ap.add_argument("--frames", default="texture", choices=["texture", "random"],
+                    help="texture: SURVEY 8d's smooth texture translating by (2,1) px per frame (default); random: uniform-random u8 "
+                         "frames (seed 1), the worst case for value ranges")
     ap.add_argument("--copy-frames", action="store_true",
                     help="stream path: the session keeps its own copy of level 0 of every frame instead of reading the caller's ring "
                          "of frames in place (ofx_params.borrow_frames = 0); the default run reports this variant under extra")
@@ -158,56 +228,120 @@ def main():
                          "ofx_params.stream_two_stage, which an unsharded stream with borrowed frames uses by default")
     ap.add_argument("--batch", type=int, default=0, choices=list(range(0, 17)),
                     help="stream path: frames per launch (ofx_params.stream_batch) = frames per step.  0 = "
-                         "engine.suggest_stream_batch: by the working set of the pipeline (4K: 4 on one GPU, 8 per rank of a sharded pair)")
+                         "engine.suggest_stream_batch: by the working set of the pipeline (4K: 8 on one GPU, 8 per rank of a sharded pair)")
     ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
                     help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
                          "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
-    args = ap.parse_args()
-    # A stream tick carries `batch` frames and a step is one frame: the timed K steps must be whole ticks, or frames would be
-    # counted that were only queued.  Use the largest batch that divides K.
+    return ap.parse_args()
+
+
+def plan_stream(args):
+    """frames per launch, borrowed frames, two or three stages for the timed stream path (args gains .borrow, .two_stage, .batch)"""
+    from cuda_optical_flow_2_amd.engine import suggest_stream_batch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
     args.borrow = not args.copy_frames
     # two ticks instead of three between a frame and its flow (the corner blocks build their own patch pyramids): a third less
     # of everything the pipeline keeps in flight, which is what lets eight 4K frames per launch stay in the Infinity Cache
     args.two_stage = (args.borrow and not args.three_stage and args.path == "stream" and args.gpus == 1 and args.iters <= 1
                       and os.environ.get("OFX_BENCH_FORCE_DIST") != "1")
+    bw, bh, bl, bwin = WORKLOADS[args.workload]
     if args.batch == 0:
-        from cuda_optical_flow_2_amd.engine import suggest_stream_batch
-        from cuda_optical_flow_2_amd.parallel import ShardPlan
-        bw, bh, bl, bwin = WORKLOADS[args.workload]
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
         args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow, args.two_stage)
-    while args.batch > 1 and args.batch * WORKLOADS[args.workload][2] > 80:  # OFX_MAX_LK_ITEMS: (pair, level) items per launch
+    while args.batch > 1 and args.batch * bl > MAX_LK_ITEMS:
         args.batch -= 1
     # (in a short launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
     # the launch waits for: three stages are the better plan there, DESIGN.md section 4.3)
-    if args.two_stage and (args.batch < 5 or args.batch * WORKLOADS[args.workload][0] * WORKLOADS[args.workload][1] < OFX_TWO_STAGE_MIN_PIXELS):
+    if args.two_stage and (args.batch < 5 or args.batch * bw * bh < OFX_TWO_STAGE_MIN_PIXELS):
         args.two_stage = False   # (8K, two frames per launch: the patch of six levels and a 15x15 window is 544 pixels wide -- 129k vs 217k Mpix/s)
-    # A STEP of the stream path is one tick = one launch = args.batch frames (one pass of the hot path over one batch of
-    # input); of the pair-at-a-time paths one pair.  W and K count steps; every per-frame figure of the line says so.
-    warmup_steps = args.warmup
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
-    from cuda_optical_flow_2_amd import engine, synth
+def ring_size(batch, two_stage):
+    """distinct frame buffers of the ring the stream paths read: ofx_params.borrow_frames keeps frame f's buffer in use until the
+    launch of submit f + d * batch (d = 2 ticks in two stages, 3 in three)"""
+    depth = 2 if two_stage else 3
+    return (depth * max(batch, 4) + 4 + 3) // 4 * 4
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    torch.cuda.set_device(local_rank)
-    # Everything is enqueued on one explicit (non-null) HIP stream: the legacy null stream serialises against every other
-    # stream of the process and costs several microseconds more per launch.
-    work_stream = torch.cuda.Stream()
-    torch.cuda.set_stream(work_stream)
-    force_dist = os.environ.get("OFX_BENCH_FORCE_DIST") == "1"  # rehearsal: run the N > 1 driver (RCCL init, broadcast) on one rank
-    distributed = world > 1 or force_dist
-    rccl_world = None
-    if distributed:
+
+def make_ring(src, n):
+    """n DISTINCT device buffers whose contents repeat every len(src) buffers"""
+    return [src[i % len(src)] if i < len(src) else src[i % len(src)].clone() for i in range(n)]
+
+
+class StreamFeed:
+    """Hands a session the ring's frames a tick at a time (ofx_session_stream_submit_frames: one FFI crossing per tick --
+    the per-frame crossing is what limits small frames and the ranks of a sharded pair).  step() counts frames and
+    submits on a tick's last one; tick j takes ring buffers j*B .. j*B + B - 1 modulo the ring."""
+
+    def __init__(self, submit_frames, ring, batch):
+        from cuda_optical_flow_2_amd import engine
+
+        self.submit, self.batch, self.frames_in = submit_frames, batch, 0
+        n = len(ring)
+        self.groups = [engine.FrameGroup([ring[(j * batch + k) % n] for k in range(batch)]) for j in range(math.lcm(n, batch) // batch)]
+
+    def step(self, _i=None):   # one frame
+        self.frames_in += 1
+        if self.frames_in % self.batch == 0:
+            self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
+
+    def tick(self, _i=None):   # a whole tick: self.batch frames, one launch
+        assert self.frames_in % self.batch == 0
+        self.frames_in += self.batch
+        self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
+
+
+# ---- the run ---------------------------------------------------------------------------------------------------------------
+
+class Run:
+    """everything the legs share: arguments, torch, the device frames, rank / world"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+
+        from cuda_optical_flow_2_amd import engine, synth
+
+        self.args, self.torch, self.dist, self.engine, self.synth = args, torch, dist, engine, synth
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run"
+        torch.cuda.set_device(self.local_rank)
+        # Everything is enqueued on one explicit (non-null) HIP stream: the legacy null stream serialises against every other
+        # stream of the process and costs several microseconds more per launch.
+        self.work_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.work_stream)
+        force_dist = os.environ.get("OFX_BENCH_FORCE_DIST") == "1"  # rehearsal: run the N > 1 driver (RCCL init, broadcast) on one rank
+        self.distributed = self.world > 1 or force_dist
+        self.rccl_world = self.init_distributed() if self.distributed else None
+        self.w, self.h, self.levels, self.window = WORKLOADS[args.workload]
+        # experiments: OFX_BENCH_MOTION="mx,my" scales the per-frame translation (2,1) px; "0,0" = identical frames
+        self.motion = tuple(float(t) for t in os.environ.get("OFX_BENCH_MOTION", "1,1").split(","))
+        self.nframes = 4
+        self.frames = self.host_frames(self.w, self.h, args.frames)
+        self.d_frames = [torch.from_numpy(f).cuda() for f in self.frames]
+        self.ring_n = int(os.environ.get("OFX_BENCH_RING", "0")) or ring_size(args.batch, args.two_stage)  # (experiments: other ring sizes)
+        # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
+        # hand them over: long enough for ofx_params.borrow_frames, and large enough that a frame is not still sitting in the
+        # 256 MB Infinity Cache when it comes round again merely because the ring is short.  Contents repeat every four buffers.
+        self.d_ring = make_ring(self.d_frames, self.ring_n)
+
+    def host_frames(self, w, h, kind="texture"):
+        """four frames: SURVEY 8d's smooth texture translating by (2,1) px per frame, or its uniform-random u8 frames (seeds 1, 2)"""
+        if kind == "random":
+            a, b = self.synth.random_pair(w, h, 1)
+            c, d = self.synth.random_pair(w, h, 2)
+            return [a, b, c, d]
+        mx, my = self.motion
+        return [self.synth.smooth_pair(w, h, 2.0 * i * mx, 1.0 * i * my)[1] for i in range(self.nframes)]
+
+    def init_distributed(self):
+        torch, dist = self.torch, self.dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -218,92 +352,62 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             dist.barrier()
             # proof that RCCL saw every rank: a one-element all-reduce of ones over the communicator the run uses
             ones = torch.ones(1, dtype=torch.int32, device="cuda")
             dist.all_reduce(ones)
             torch.cuda.synchronize()
-            rccl_world = int(ones.item())
+            return int(ones.item())
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    w, h, levels, window = WORKLOADS[args.workload]
-    # a short ring of resident frames: a smooth texture translating by (2,1) px per frame
-    nframes = 4
-    # experiments: OFX_BENCH_MOTION="mx,my" scales the per-frame translation (2,1) px; "0,0" = identical frames
-    mx, my = (float(t) for t in os.environ.get("OFX_BENCH_MOTION", "1,1").split(","))
-    frames = [synth.smooth_pair(w, h, 2.0 * i * mx, 1.0 * i * my)[1] for i in range(nframes)]
-    d_frames = [torch.from_numpy(f).cuda() for f in frames]
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    def make_ring(src, n):
-        """n DISTINCT device buffers whose contents repeat every len(src) buffers"""
-        return [src[i % len(src)] if i < len(src) else src[i % len(src)].clone() for i in range(n)]
+    def max_over_ranks(self, x):
+        if not self.distributed:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def ring_size(batch, depth=None):
-        depth = depth or (2 if args.two_stage else 3)   # ticks a borrowed frame stays in use
-        return (depth * max(batch, 4) + 4 + 3) // 4 * 4
-
-    # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
-    # hand them over: long enough for ofx_params.borrow_frames (frame f's buffer is read until the launch of submit f + 3 * batch), and
-    # large enough that a frame is not still sitting in the 256 MB Infinity Cache when it comes round again (four buffers
-    # would be: with borrowed frames that alone made the LK stage ~10 % faster).  Contents repeat every four buffers.
-    ring_n = int(os.environ.get("OFX_BENCH_RING", "0")) or ring_size(args.batch)  # (experiments: other ring sizes)
-    d_ring = make_ring(d_frames, ring_n)
-
-    class StreamFeed:
-        """Hands a session the ring's frames a tick at a time (ofx_session_stream_submit_frames: one FFI crossing per tick --
-        the per-frame crossing is what limits small frames and the ranks of a sharded pair).  step(i) counts frames and
-        submits on a tick's last one; tick j takes ring buffers j*B .. j*B + B - 1 modulo the ring."""
-
-        def __init__(self, submit_frames, ring, batch):
-            self.submit, self.batch, self.frames_in = submit_frames, batch, 0
-            n = len(ring)
-            self.groups = [engine.FrameGroup([ring[(j * batch + k) % n] for k in range(batch)]) for j in range(math.lcm(n, batch) // batch)]
-
-        def step(self, _i=None):   # one frame
-            self.frames_in += 1
-            if self.frames_in % self.batch == 0:
-                self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
-
-        def tick(self, _i=None):   # a whole tick: self.batch frames, one launch
-            assert self.frames_in % self.batch == 0
-            self.frames_in += self.batch
-            self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
-
-    feed = None
-    if not distributed:
-        sess = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters,
-                              stream_batch=args.batch if args.path == "stream" else 1,
-                              borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)),
-                              two_stage=args.two_stage)
-        sess.push_frame_host(frames[0])
-
-        if args.path == "stream":
-            # one launch per tick: pyramid(newest frames) | corner(the pairs before) | fused LK(the pairs before those, global shift
-            # in its loads) side by side in one grid (ofx_session_stream_submit); every step completes exactly one pair once the
-            # pipeline is full
-            sess.stream_begin()
-            feed = StreamFeed(sess.stream_submit_frames, d_ring, args.batch)
-            step = feed.tick
-            for i in range(3):   # (fill the pipeline)
-                step(i)
-        elif args.path == "staged":
-            # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
-            # pair's LK launch
-            def step(i):
-                sess.submit_device(d_frames[(i + 1) % nframes])
-        else:
-            def step(i):
-                sess.set_frame_device(d_frames[(i + 1) % nframes])
-                sess.build_pyramid()
-                sess.run_flow()
-                sess.swap()
-
-        driver = None
-    else:
+    # ---- the timed configuration ------------------------------------------------------------------------------------------
+    def build_headline(self):
+        """the session (or the sharded driver) of the timed configuration and its step function"""
+        args, engine, w, h, levels, window = self.args, self.engine, self.w, self.h, self.levels, self.window
+        self.feed, self.driver = None, None
+        if not self.distributed:
+            self.sess = sess = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, iters=args.iters,
+                                              stream_batch=args.batch if args.path == "stream" else 1,
+                                              borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)),
+                                              two_stage=args.two_stage)
+            sess.push_frame_host(self.frames[0])
+            if args.path == "stream":
+                # one launch per tick: pyramid(newest frames) | corner(the pairs before) | fused LK(the pairs before those, global shift
+                # in its loads) side by side in one grid (ofx_session_stream_submit)
+                sess.stream_begin()
+                self.feed = StreamFeed(sess.stream_submit_frames, self.d_ring, args.batch)
+                self.step = self.feed.tick
+                for i in range(3):   # (fill the pipeline)
+                    self.step(i)
+            elif args.path == "staged":
+                # pair at a time, staging (frame load, pyramid, corner, shifts) on the session's aux stream under the previous
+                # pair's LK launch
+                self.step = lambda i: sess.submit_device(self.d_frames[(i + 1) % self.nframes])
+            else:
+                def step(i):
+                    sess.set_frame_device(self.d_frames[(i + 1) % self.nframes])
+                    sess.build_pyramid()
+                    sess.run_flow()
+                    sess.swap()
+                self.step = step
+            return
         from cuda_optical_flow_2_amd import parallel
 
         # One pair row-sharded over the ranks (strong scaling).  Default: every rank runs the one-launch-per-frame stream
@@ -311,82 +415,70 @@ def main():
         # path; --shard-corner broadcast keeps rank 0's corner kernel + one RCCL broadcast per pair (staged halves).
         if args.shard_halo == "exchange":
             args.shard_corner = "broadcast"
-        driver = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner=args.shard_corner,
-                                      stream_batch=args.batch, halo_mode=args.shard_halo, iters=args.iters,
-                                      borrow_frames=args.borrow and args.shard_corner == "local" and args.shard_halo != "exchange")
-        sess = driver.session
+        self.driver = driver = parallel.ShardedFlow(w, h, levels, window, args.mode, self.rank, self.world, device=self.local_rank, corner=args.shard_corner,
+                                                    stream_batch=args.batch, halo_mode=args.shard_halo, iters=args.iters,
+                                                    borrow_frames=args.borrow and args.shard_corner == "local" and args.shard_halo != "exchange")
+        self.sess = driver.session
         if args.shard_corner == "local":
             driver.stream_begin()
-            feed = StreamFeed(driver.stream_submit_frames, d_ring, args.batch)
-            step = feed.tick
+            self.feed = StreamFeed(driver.stream_submit_frames, self.d_ring, args.batch)
+            self.step = self.feed.tick
             for i in range(3):   # (fill the pipeline)
-                step(i)
+                self.step(i)
         else:
-            driver.push_frame(d_frames[0])
+            driver.push_frame(self.d_frames[0])
+            self.step = lambda i: driver.step(self.d_frames[(i + 1) % self.nframes])
 
-            def step(i):
-                driver.step(d_frames[(i + 1) % nframes])
-
-    def fence():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(x):
-        if not distributed:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    # Untimed clock ramp: the first ~10 ms of a kernel stream run 15-20 % slower than the sustained rate on MI355X (a
-    # 200-step run right after start-up measured 175-180k Mpix/s, the same steps after 0.1 s of load 210k+), and the default
-    # timed region is only tens of ms long.  So the device first works for OFX_BENCH_RAMP_S seconds on the very steps that
-    # are measured afterwards; then come the W warm-up steps and the K timed steps of the contract.
-    ramp_s = float(os.environ.get("OFX_BENCH_RAMP_S", "0.3"))
-    t_ramp = time.perf_counter() + ramp_s
-    i_ramp = 0
-    fps = args.batch if feed is not None else 1   # frames (pairs) per step
-    while time.perf_counter() < t_ramp:
-        for _ in range(max(8, 64 // fps)):
-            step(i_ramp)
-            i_ramp += 1
-        torch.cuda.synchronize()
-    for i in range(warmup_steps):
-        step(i)
-    fence()
-    # pass 1 -- the throughput: EXACTLY args.steps steps, no instrumentation inside the timed region
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(warmup_steps + i)
-    fence()
-    dt = time.perf_counter() - t0
-    # pass 2 -- the dominant kernel's duration: the same steps again with a pair of HIP events recorded around every
-    # launch on the stream it runs on (two extra packets per launch, so this pass is not the one timed above)
-    # (at least ~100 launches, so that a short driver run -- K = 20 -- still gives a stable average)
-    roof_steps = max(args.steps, -(-400 // args.batch) if feed is not None else 400)
-    sess.timing(roof_steps * (2 * max(1, args.iters) + 3))
-    for i in range(roof_steps):
-        step(warmup_steps + args.steps + i)
-    fence()
-    kinds = {k: sess.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
-    k_avg_us, k_min_us, k_n = sess.timing_read()
-    sess.timing(0)
-    dt = max_over_ranks(dt)
-
-    stream_like = feed is not None
-    own_rows = None if driver is None else driver.plan.own
+    def time_headline(self):
+        """untimed clock ramp, W warm-up steps, pass 1 (exactly K steps, nothing else in the region), pass 2 (events per launch)"""
+        args, torch, sess, step = self.args, self.torch, self.sess, self.step
+        # Untimed clock ramp: the first ~10 ms of a kernel stream run 15-20 % slower than the sustained rate on MI355X (a
+        # 200-step run right after start-up measured 175-180k Mpix/s, the same steps after 0.1 s of load 210k+), and the default
+        # timed region is only tens of ms long.  So the device first works for OFX_BENCH_RAMP_S seconds on the very steps that
+        # are measured afterwards; then come the W warm-up steps and the K timed steps of the contract.
+        self.ramp_s = float(os.environ.get("OFX_BENCH_RAMP_S", "0.3"))
+        t_ramp = time.perf_counter() + self.ramp_s
+        i_ramp = 0
+        self.fps = fps = args.batch if self.feed is not None else 1   # frames (pairs) per step
+        while time.perf_counter() < t_ramp:
+            for _ in range(max(8, 64 // fps)):
+                step(i_ramp)
+                i_ramp += 1
+            torch.cuda.synchronize()
+        for i in range(args.warmup):
+            step(i)
+        self.fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        self.fence()
+        dt = time.perf_counter() - t0
+        # pass 2 -- the dominant kernel's duration: the same steps again with a pair of HIP events recorded around every
+        # launch on the stream it runs on (two extra packets per launch, so this pass is not the one timed above)
+        # (at least ~100 launches, so that a short driver run -- K = 20 -- still gives a stable average)
+        self.roof_steps = roof_steps = max(args.steps, -(-400 // args.batch) if self.feed is not None else 400)
+        sess.timing(roof_steps * (2 * max(1, args.iters) + 3))
+        for i in range(roof_steps):
+            step(args.warmup + args.steps + i)
+        self.fence()
+        self.kinds = {k: sess.timing_read_kind(k) for k in self.engine.Session.TIME_KINDS}
+        self.k_avg_us, self.k_min_us, self.k_n = sess.timing_read()
+        sess.timing(0)
+        self.dt = self.max_over_ranks(dt)
 
     # ---- self-check: the session that was just timed against an independent plain session ----------------------------
-    def same_bits(a, b):
-        return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
-
-    def self_check():
+    def self_check(self):
         """After the timed region: a short stream through the SAME session (same plan: frames per launch, borrowed ring,
         shard rows), then every level of its newest pairs against a plain pair-at-a-time session (the sequence the parity
         tests tie to the oracle).  Returns a description or raises."""
-        plain = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=args.iters)
+        args, torch, engine, sess, driver = self.args, self.torch, self.engine, self.sess, self.driver
+        w, h, levels, window = self.w, self.h, self.levels, self.window
+        own_rows = None if driver is None else driver.plan.own
+
+        def same_bits(a, b):
+            return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+
+        plain = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, iters=args.iters)
 
         def plain_pair(a, b):
             plain.set_frame_device(a); plain.build_pyramid(); plain.swap()
@@ -394,7 +486,7 @@ def main():
             return [plain.flow(k)[0] for k in range(levels)]
 
         checked = []
-        if stream_like:
+        if self.feed is not None:
             drain = sess.stream_drain if driver is None else driver.stream_drain
             while drain() != -2:
                 pass
@@ -402,11 +494,11 @@ def main():
             nf = 4 * args.batch
             submit = sess.stream_submit if driver is None else driver.stream_submit
             for i in range(nf):
-                submit(d_ring[i % ring_n])
+                submit(self.d_ring[i % self.ring_n])
             while drain() != -2:
                 pass
             for p in sorted({nf - 1, nf - args.batch}):
-                ref = plain_pair(d_ring[(p - 1) % ring_n], d_ring[p % ring_n])
+                ref = plain_pair(self.d_ring[(p - 1) % self.ring_n], self.d_ring[p % self.ring_n])
                 for k in range(levels):
                     got = sess.flow_of(p, k)[0]
                     want = ref[k] if own_rows is None else ref[k][own_rows[k][0]:own_rows[k][1]]
@@ -416,12 +508,9 @@ def main():
             what = f"stream session (batch {args.batch}) pairs {checked}, all {levels} levels == plain sequence, bit for bit"
         else:
             # pair-at-a-time paths: the flow of the last timed pair against the reference's literal level-by-level sequence
-            last = warmup_steps + args.steps + roof_steps - 1
-            a, b = d_frames[last % nframes], d_frames[(last + 1) % nframes]
-            if driver is None:
-                got = [sess.flow(k)[0] for k in range(levels)]
-            else:
-                got = [driver.backend.flow(k) for k in range(levels)]
+            last = args.warmup + args.steps + self.roof_steps - 1
+            a, b = self.d_frames[last % self.nframes], self.d_frames[(last + 1) % self.nframes]
+            got = [sess.flow(k)[0] for k in range(levels)] if driver is None else [driver.backend.flow(k) for k in range(levels)]
             if args.iters > 1:
                 ref = plain_pair(a, b)
             else:
@@ -435,107 +524,388 @@ def main():
             what = f"last timed pair, all {levels} levels == level-by-level plain sequence, bit for bit"
         torch.cuda.synchronize()
         plain.close()
-        if driver is not None:
-            st = driver.corner_status()
-            if st != 0:
-                raise SystemExit(f"bench.py self-check FAILED: rank {rank} status word {st:#x} (a shift left the patch / the shard's halo)")
-            what += "; shard status word 0"
-        elif args.two_stage:
-            st = sess.corner_status()
-            if st != 0:
-                raise SystemExit(f"bench.py self-check FAILED: status word {st:#x} (a corner shift left the patch: ofx_params.stream_two_stage)")
-            what += "; status word 0 (every corner shift stayed inside its patch)"
+        st = driver.corner_status() if driver is not None else sess.corner_status()
+        if st != 0:
+            raise SystemExit(f"bench.py self-check FAILED: rank {self.rank} status word {st:#x} (a pair that is not the reference's result: "
+                             "include/ofx.h, ofx_session_corner_status)")
+        what += "; status word 0"
+        if args.two_stage and driver is None:
+            what += " (a corner shift that leaves its patch is repaired on the device: ofx_session_pair_status)"
         return what
 
-    # (timing experiments with ablated kernels, OFX_BUILD_DEFS=-DOFX_X_*: their results are wrong by construction)
-    check_msg = "SKIPPED (OFX_BENCH_SKIP_CHECK)" if os.environ.get("OFX_BENCH_SKIP_CHECK") == "1" else self_check()
-    if distributed:
-        dist.barrier()
-
     # ---- generic stream leg for the extras: wall-clock throughput + event-timed launches ---------------------------------
-    def stream_leg(wl, mode, batch, borrow, ring, steps, events=True, two_stage=None):
+    def stream_leg(self, wl, mode, batch, borrow, ring, steps, events=True, two_stage=None, iters=1, min_launches=50):
+        torch, engine = self.torch, self.engine
         w2, h2, l2, win2 = wl
-        two_stage = (args.two_stage and borrow) if two_stage is None else two_stage   # like the main run wherever the frames are borrowed
+        two_stage = (self.args.two_stage and borrow) if two_stage is None else two_stage   # like the main run wherever the frames are borrowed
+        two_stage = bool(two_stage and iters <= 1)
         assert len(ring) >= (2 if two_stage else 3) * batch + 1 or not borrow, "the ring is too short for borrowed frames"
-        s2 = engine.Session(w2, h2, l2, win2, mode, device=local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage)
+        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage, iters=iters)
         s2.stream_begin()
         fd = StreamFeed(s2.stream_submit_frames, ring, batch)
         t_end = time.perf_counter() + 0.15
         while time.perf_counter() < t_end:
-            for _ in range(16 * batch):
-                fd.step()
+            for _ in range(16 if iters <= 1 else 2):
+                fd.tick()
             torch.cuda.synchronize()
-        n = max(400 // batch * batch, steps // batch * batch)   # (a short driver run must not shrink the extras to a handful of launches)
+        # (a short driver run must not shrink the legs to a handful of launches; an expensive configuration is kept short)
+        ticks = max(min_launches, steps) if iters <= 1 else max(4, min(steps, min_launches))
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-            fd.step()
+        for _ in range(ticks):
+            fd.tick()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
-        res = {"value": round(w2 * h2 / (ms * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms, 5),
-               "frames_per_s": round(1e3 / ms, 1), "steps": n, "frames_per_launch": batch}
+        ms = (time.perf_counter() - t0) / (ticks * batch) * 1e3   # per frame (pair)
+        res = {"value": round(w2 * h2 / (ms * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms, 5),
+               "frames_per_s": round(1e3 / ms, 1), "pairs_timed": ticks * batch, "frames_per_launch": batch}
         if events:
-            s2.timing(n // batch)
-            for _ in range(n):
-                fd.step()
+            s2.timing(ticks * (2 * max(1, iters) + 3))
+            for _ in range(ticks):
+                fd.tick()
             torch.cuda.synchronize()
-            avg, mn, cnt = s2.timing_read()
+            if iters <= 1:
+                avg, mn, cnt = s2.timing_read()
+                res["roofline"] = roofline_block(batch * pair_bytes(w2, h2, l2), avg, kernel="stream_kernel",
+                                                 algorithmic_bytes_per_launch=batch * pair_bytes(w2, h2, l2), avg_launch_us=round(avg, 2), launches_timed=cnt)
+            else:
+                # refinement iterations: the roofline is that of the whole pair -- every launch event-timed and tagged
+                kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
+                us_pair = sum(v[0] * v[2] for v in kk.values() if v[2]) / (ticks * batch)
+                nbytes = iters_pair_bytes(w2, h2, l2, iters)
+                res["roofline"] = roofline_block(nbytes, us_pair, algorithmic_bytes_per_pair=nbytes, kernel_us_per_pair=round(us_pair, 2),
+                                                 launches={k: {"avg_us": round(v[0], 2), "per_tick": v[2] // ticks} for k, v in kk.items() if v[2]})
             s2.timing(0)
-            nbytes = batch * pair_bytes(w2, h2, l2)
-            res["roofline"] = {"bound": "hbm", "kernel": "stream_kernel", "achieved": round(nbytes / (avg * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": round(nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": round(avg, 2), "launches_timed": cnt}
         s2.close()
         return res
 
-    # N > 1 only, reported under `extra`: the other way to use N GPUs on a frame stream -- every rank runs the unsharded
-    # pipeline on its own pairs (no sharding, nothing shared): N times the pairs per second at unchanged latency per pair.
-    # Same step count, same fences, max over ranks.
-    dt_indep = dt_exch = None
-    if driver is not None:
+    def device_ring(self, wl, batch, two_stage, kind="texture"):
+        w2, h2 = wl[:2]
+        src = [self.torch.from_numpy(f).cuda() for f in self.host_frames(w2, h2, kind)]
+        return make_ring(src, ring_size(batch, two_stage))
+
+    # ---- extra legs (single GPU), one function each ------------------------------------------------------------------------
+    def leg_iters_pair_at_a_time(self, wl, it, d_frames, steps):
+        """a BASELINE configuration with its iterations (the lk_iter extension), pair at a time, every launch of a
+        pair event-timed: bytes per SURVEY 8d = 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid"""
+        torch, engine = self.torch, self.engine
+        w, h, levels, window = wl
+        nf = len(d_frames)
+        s2 = engine.Session(w, h, levels, window, self.args.mode, device=self.local_rank, iters=it)
+        s2.set_frame_device(d_frames[0]); s2.build_pyramid(); s2.swap()
+
+        def step2(i):
+            s2.set_frame_device(d_frames[(i + 1) % nf]); s2.build_pyramid(); s2.run_flow(); s2.swap()
+        n2 = max(10, min(steps, 50))
+        for i in range(5):
+            step2(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n2):
+            step2(5 + i)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / n2 * 1e3
+        s2.timing(n2 * (2 * it + 3))
+        for i in range(n2):
+            step2(5 + n2 + i)
+        torch.cuda.synchronize()
+        kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
+        s2.timing(0)
+        s2.close()
+        px = level_px(w, h, levels)
+        per_kind_bytes = {"lk": LK_BYTES_PER_PX * sum(px), "lk_acc": LK_ACC_BYTES_PER_PX * sum(px), "warp": WARP_BYTES_PER_PX * sum(px),
+                          "shift": 2 * sum(px[:-1]), "pyramid": PYR_BYTES_PER_DST_PX * sum(px[1:])}
+        launches = {}
+        for k, (avg, mn, cnt) in kk.items():
+            if cnt:
+                launches[k] = {"avg_us": round(avg, 2), "per_pair": cnt // n2}
+                if k in per_kind_bytes:
+                    launches[k]["algorithmic_bytes"] = per_kind_bytes[k]
+                    launches[k]["frac"] = round(per_kind_bytes[k] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        pair_alg = iters_pair_bytes(w, h, levels, it)
+        kernel_us = sum(v[0] * (v[2] // n2) for v in kk.values() if v[2])
+        return {"workload": f"{w}x{h}, {levels} levels, {window}x{window}, iters={it} (extension lk_iter: bilinear-warp refinement), pair at a time",
+                "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms2, 5), "frames_per_s": round(1e3 / ms2, 1),
+                "pairs_timed": n2,
+                "roofline": roofline_block(pair_alg, kernel_us, algorithmic_bytes_per_pair=pair_alg, kernel_us_per_pair=round(kernel_us, 2),
+                                           launches=launches, timed_in="second pass, hipEventRecord around every launch of the pair")}
+
+    def leg_baseline_config(self, name, steps):
+        """BASELINE config `name` as it is written: its iterations (streamed: one warp + one accumulating LK launch per iteration
+        over all pairs of a tick) and, next to it, the same geometry with iters = 1 (the only value the reference defines)"""
+        wl = WORKLOADS[name]
+        it = BASELINE_ITERS[name]
+        w2, h2, l2, win2 = wl
+        out = {}
+        b1 = self.engine.suggest_stream_batch(w2, h2, l2, None, True, True)
+        two1 = b1 >= 5 and b1 * w2 * h2 >= OFX_TWO_STAGE_MIN_PIXELS
+        if not two1:
+            b1 = self.engine.suggest_stream_batch(w2, h2, l2, None, True, False)
+        ring1 = self.device_ring(wl, b1, two1)
+        r1 = self.stream_leg(wl, self.args.mode, b1, True, ring1, steps, two_stage=two1)
+        r1["workload"] = f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters=1, stream path, {b1} frames per launch"
+        out["iters1"] = r1
+        bi = 4 if 4 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 3840 * 2160 else 2
+        ringi = ring1 if len(ring1) >= 3 * bi + 1 else self.device_ring(wl, bi, False)
+        ri = self.stream_leg(wl, self.args.mode, bi, True, ringi, steps, two_stage=False, iters=it, min_launches=12 if w2 * h2 <= 3840 * 2160 else 6)
+        ri["workload"] = (f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters={it} (extension lk_iter), streamed: {bi} pairs per "
+                          "launch, frames read in place")
+        out[f"iters{it}"] = ri
+        del ring1, ringi
+        return out
+
+    def leg_plain_path(self, steps):
+        """the pair-at-a-time path (what gpu::calc_opt_flow-style callers and latency-bound callers get): set_frame (borrowed) ->
+        build_pyramid -> run_flow -> swap, three launches per pair, every launch event-timed"""
+        torch, engine = self.torch, self.engine
+        w, h, levels, window = self.w, self.h, self.levels, self.window
+        s2 = engine.Session(w, h, levels, window, self.args.mode, device=self.local_rank, borrow_frames=w % 64 == 0)
+        s2.push_frame_host(self.frames[0])
+
+        def step2(i):
+            s2.set_frame_device(self.d_frames[(i + 1) % self.nframes]); s2.build_pyramid(); s2.run_flow(); s2.swap()
+        n2 = max(200, min(steps, 1000))
+        for i in range(50):
+            step2(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n2):
+            step2(i)
+        torch.cuda.synchronize()
+        ms2 = (time.perf_counter() - t0) / n2 * 1e3
+        s2.timing(4 * n2)
+        for i in range(n2):
+            step2(i)
+        torch.cuda.synchronize()
+        kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
+        s2.timing(0)
+        s2.close()
+        px = level_px(w, h, levels)
+        lk_us = kk["lk"][0]
+        return {"workload": "as value, pair at a time: set_frame (read in place) -> build_pyramid -> run_flow -> swap, three launches per pair",
+                "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "us_per_pair": round(ms2 * 1e3, 2), "pairs_timed": n2,
+                "launches_us": {k: round(v[0], 2) for k, v in kk.items() if v[2]},
+                "roofline": roofline_block(LK_BYTES_PER_PX * sum(px), lk_us, kernel="lk_level_kernel (all levels, one launch)",
+                                           algorithmic_bytes_per_launch=LK_BYTES_PER_PX * sum(px), avg_launch_us=round(lk_us, 2)),
+                "pyramid_roofline": roofline_block(PYR_BYTES_PER_DST_PX * sum(px[1:]), kk["pyramid"][0], kernel="pyramid_fused_kernel",
+                                                   avg_launch_us=round(kk["pyramid"][0], 2))}
+
+    def leg_api_compat(self):
+        """API-compat timing (SURVEY 8d): host pointers through the reference's own call surface -- gpu::gauss_pyramid for both
+        frames + gpu::calc_opt_flow per level (OptFlowGpu.cu:1909; window 19 is hard-coded there) -- PCIe included"""
+        from cuda_optical_flow_2_amd.compat import GpuCompat
+
+        gc = GpuCompat()
+        api = {}
+        for nm in ("1080p", "4k"):
+            wa, ha, la, _ = WORKLOADS[nm]
+            pa, na = self.synth.smooth_pair(wa, ha)
+            p3, n3 = self.synth.to_3ch(pa), self.synth.to_3ch(na)
+            gc.flow_pair(p3, n3, la)
+            reps = 3
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                gc.flow_pair(p3, n3, la)
+            dta = (time.perf_counter() - t0) / reps
+            api[nm] = {"value": round(wa * ha / dta / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(dta * 1e3, 2),
+                       "workload": f"{wa}x{ha}, {la} levels, window 19 (the reference's GPU constant), 3-channel host images in, "
+                                   "host flow pyramid out, both pyramids rebuilt per pair as gpu::gauss_pyramid's signature demands"}
+        return api
+
+    def leg_frontend(self):
+        """the front end of main.cu's frame (main.cu:232-240, in front of the pyramid): grayscale + the 9x9 bilateral pre-filter
+        (sigma 2 / 10), device-resident, 3-channel images as the reference passes them.  Bytes per pixel: grayscale
+        3 read + 3 written, bilateral 3 (src) + 3 (gray) read + 3 written."""
+        from cuda_optical_flow_2_amd import lib as _l
+
+        torch = self.torch
+        L_ = _l.load()
+        fe = {}
+        for nm in ("1080p", "4k"):
+            wa, ha = WORKLOADS[nm][:2]
+            img = torch.randint(0, 256, (ha, wa, 3), dtype=torch.uint8, device="cuda")
+            gray, filt = torch.empty_like(img), torch.empty_like(img)
+            st_ = torch.cuda.current_stream().cuda_stream
+
+            def timed(fn, reps):
+                fn(); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    fn()
+                e1.record(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) / reps * 1e3
+            t_g = timed(lambda: _l.check(L_.ofx_grayscale_avg_3ch(img.data_ptr(), gray.data_ptr(), wa, ha, st_), "grayscale"), 20)
+            t_b = timed(lambda: _l.check(L_.ofx_bilateral_3ch(gray.data_ptr(), gray.data_ptr(), filt.data_ptr(), wa, ha, 9, 9, 2.0, 10.0, st_), "bilateral"), 5)
+            fe[nm] = {"grayscale_us": round(t_g, 1), "grayscale_frac": round(6 * wa * ha / (t_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                      "bilateral_9x9_us": round(t_b, 1), "bilateral_frac": round(9 * wa * ha / (t_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                      "value": round(wa * ha / ((t_g + t_b) * 1e-6) / 1e6, 1), "unit": "Mpix/s"}
+            del img, gray, filt
+        return fe
+
+    def extras_single_gpu(self):
+        args, engine = self.args, self.engine
+        w, h, levels, window = self.w, self.h, self.levels, self.window
+        wl = (w, h, levels, window)
+        extra = {}
+        if not (args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS):
+            return extra
+        # BASELINE.json's configs carry "N iters"; the reference has no iterations (SURVEY fact 3), so they run as the
+        # lk_iter extension here, next to the reference-defined line above (same process, same frames)
+        it = BASELINE_ITERS[args.workload]
+        lit = self.leg_iters_pair_at_a_time(wl, it, self.d_frames, args.steps)
+        b9 = 4 if 4 * levels <= MAX_LK_ITEMS else 2
+        streamed = self.stream_leg(wl, args.mode, b9, args.borrow, self.d_ring if len(self.d_ring) >= 3 * b9 + 1 else make_ring(self.d_frames, ring_size(b9, False)),
+                                   args.steps, two_stage=False, iters=it, min_launches=12)
+        streamed["workload"] = f"as above through the stream pipeline, {b9} pairs per launch, frames " + ("read in place" if args.borrow else "copied")
+        lit["streamed"] = streamed
+        extra["baseline_config_with_iters"] = lit
+        if args.path == "stream" and args.borrow:
+            # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
+            # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
+            b3 = engine.suggest_stream_batch(w, h, levels, None, False)
+            r3 = self.stream_leg(wl, args.mode, b3, False, self.d_ring[:16] if len(self.d_ring) > 16 else self.d_ring, args.steps)
+            r3["workload"] = f"as value, but the session copies level 0 of every frame ({b3} frames per launch)"
+            extra["stream_with_copied_frames"] = r3
+            # cache-cold inputs: the ring is long enough that neither the frames nor the session's image sets survive in the
+            # 256 MB Infinity Cache between their uses, i.e. every image row the level kernel reads comes from HBM -- what a
+            # pipeline fed from a large surface pool sees
+            cold_n = max(32, 2 * self.ring_n)
+            if w * h * cold_n < 40e9:
+                cold_ring = make_ring(self.d_frames, cold_n)
+                r6 = self.stream_leg(wl, args.mode, args.batch, True, cold_ring, args.steps)
+                r6["workload"] = (f"as value, frames read in place from a ring of {cold_n} distinct buffers ({w * h * cold_n / 1e6:.0f} MB: nothing "
+                                  "survives in the Infinity Cache between uses)")
+                extra["cold_inputs"] = r6
+                del cold_ring
+        if args.path == "stream":
+            if args.frames == "texture":
+                # SURVEY 8d's worst case for value ranges next to the smooth texture: uniform-random u8 frames (seed 1).  Every window sum
+                # of such a pair is far beyond 2^24, every derivative near its range: no data-dependent shortcut can flatter this leg.
+                rr = self.device_ring(wl, args.batch, args.two_stage, "random")
+                r10 = self.stream_leg(wl, args.mode, args.batch, args.borrow, rr, args.steps)
+                r10["workload"] = "as value, on uniform-random u8 frames (synth.random_pair, seeds 1 and 2) instead of the smooth texture"
+                extra["random_pair"] = r10
+                del rr
+            # the same pipeline with the solve in its <= 1 ulp(float) formulation (OFX_MODE_LK_FLOAT_FAST: SURVEY 8c's stated
+            # tolerance for the solve, identical NaN / Inf positions; window sums, shift and pyramid stay bit-exact)
+            r8 = self.stream_leg(wl, "lk_float_fast", args.batch, args.borrow, self.d_ring, args.steps)
+            r8["workload"] = "as value, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
+            extra["fast_solve"] = r8
+            # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
+            bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow, args.two_stage)
+            r7 = self.stream_leg(wl, "compat_cpu", bc, args.borrow, self.d_ring if bc == args.batch else make_ring(self.d_frames, ring_size(bc, args.two_stage)), args.steps)
+            r7["workload"] = f"as value, mode compat_cpu (OptFlowCPU.cpp:312-399 bug for bug; stream path, {bc} frames per launch)"
+            extra["compat_cpu"] = r7
+            extra["plain_path"] = self.leg_plain_path(args.steps)
+        if args.path == "stream" and args.workload == "4k":
+            # the metric names 1080p pairs next to 4K ones, and BASELINE.json's configs carry their own iterations: the 1080p
+            # and the 8K configuration as written and with iters = 1 (short legs: an 8K pair with ten iterations is milliseconds)
+            c2 = self.leg_baseline_config("1080p", args.steps)
+            extra["workload_1080p"] = c2["iters1"]
+            extra["workload_1080p_iters5"] = c2["iters5"]
+            c5 = self.leg_baseline_config("8k", min(args.steps, 40))
+            extra["workload_8k"] = c5["iters1"]
+            extra["workload_8k_iters10"] = c5["iters10"]
+        extra["api_compat"] = self.leg_api_compat()
+        extra["frontend"] = self.leg_frontend()
+        return extra
+
+    # ---- N > 1 legs -----------------------------------------------------------------------------------------------------------
+    def extras_distributed(self):
+        """N > 1 only: (a) every rank runs the unsharded pipeline on its own pairs (no sharding, nothing shared): N times the pairs per
+        second at unchanged latency per pair; (b) north_star's literal formulation with RCCL carrying the halos"""
+        args, engine, torch = self.args, self.engine, self.torch
+        w, h, levels, window = self.w, self.h, self.levels, self.window
+        from cuda_optical_flow_2_amd import parallel
+
+        extra = {}
         # (frames per launch as at N = 1: eight only pay when a launch carries a fraction of a pair, DESIGN.md section 4.3)
         b4 = engine.suggest_stream_batch(w, h, levels, None, args.borrow)
-        s4 = engine.Session(w, h, levels, window, args.mode, device=local_rank, borrow_frames=args.borrow, stream_batch=b4)
+        s4 = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, borrow_frames=args.borrow, stream_batch=b4)
         s4.stream_begin()
-        r4 = make_ring(d_frames, ring_size(b4))
+        r4 = make_ring(self.d_frames, ring_size(b4, False))
         fd4 = StreamFeed(s4.stream_submit_frames, r4, b4)
         t_ramp = time.perf_counter() + 0.1
         while time.perf_counter() < t_ramp:
             for i in range(16 * b4):
                 fd4.step()
             torch.cuda.synchronize()
-        n4 = max(args.steps * fps // b4 * b4, b4)   # as many frames as the timed region held
-        fence()
+        n4 = max(args.steps * self.fps // b4 * b4, b4)   # as many frames as the timed region held
+        self.fence()
         t0 = time.perf_counter()
         for i in range(n4):
             fd4.step()
-        fence()
-        dt_indep = max_over_ranks(time.perf_counter() - t0) / n4   # seconds per frame and rank
+        self.fence()
+        ms4 = self.max_over_ranks(time.perf_counter() - t0) / n4 * 1e3   # per frame and rank
         s4.close()
         del r4
+        extra["independent_pairs_per_rank"] = {
+            "workload": f"every one of the {self.world} rank(s) runs the unsharded stream pipeline on its own frame pairs (no sharding, no "
+                        "communication): aggregate pairs/s, weak scaling, latency per pair as on one GPU",
+            "value": round(self.world * w * h / (ms4 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step_per_rank": round(ms4, 5),
+            "frames_per_rank": n4}
         # north_star's literal formulation, so that a scaling run shows RCCL carrying the halos: every rank holds only its own
         # rows (+ halo) of the pair, exchanges the halo rows of every pyramid level with its neighbours (batched send/recv) and
         # receives the shift vectors by broadcast.  Pair-at-a-time, latency-bound: a short leg.
         if not args.no_extras and args.shard_halo != "exchange":
             try:
-                drv2 = parallel.ShardedFlow(w, h, levels, window, args.mode, rank, world, device=local_rank, corner="broadcast",
+                drv2 = parallel.ShardedFlow(w, h, levels, window, args.mode, self.rank, self.world, device=self.local_rank, corner="broadcast",
                                             halo_mode="exchange")
-                drv2.push_frame(d_frames[0])
+                drv2.push_frame(self.d_frames[0])
                 n5 = max(8, min(args.steps, 64))
                 for i in range(4):
-                    drv2.step(d_frames[(i + 1) % nframes])
-                fence()
+                    drv2.step(self.d_frames[(i + 1) % self.nframes])
+                self.fence()
                 t0 = time.perf_counter()
                 for i in range(n5):
-                    drv2.step(d_frames[(i + 1) % nframes])
-                fence()
-                dt_exch = (max_over_ranks(time.perf_counter() - t0), n5, drv2.corner_status())
+                    drv2.step(self.d_frames[(i + 1) % self.nframes])
+                self.fence()
+                ms5 = self.max_over_ranks(time.perf_counter() - t0) / n5 * 1e3
+                extra["halo_exchange"] = {
+                    "workload": f"north_star's literal formulation over {self.world} rank(s): own rows only, halo rows of every pyramid level exchanged "
+                                "with the neighbouring ranks (batched RCCL send/recv per level), shift vectors by RCCL broadcast; pair at a time",
+                    "value": round(w * h / (ms5 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms5, 5), "steps": n5,
+                    "status_word": drv2.corner_status()}
                 drv2.session.close()
             except ValueError as e:   # a rank owns fewer rows than the halo at some level
-                dt_exch = (None, 0, str(e))
+                extra["halo_exchange"] = {"skipped": str(e)}
+        return extra
 
-    if rank == 0:
-        ms = dt / args.steps * 1e3
+    # ---- the line ---------------------------------------------------------------------------------------------------------------
+    def traffic(self):
+        """HBM bytes per launch of the dominant kernel from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        separate passes, tools/profile_round.sh) -- a STORED figure, not a measurement of this run: reported with its provenance,
+        and dropped when the kernel sources have changed since it was taken."""
+        args = self.args
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if self.driver is not None or not os.path.exists(tpath):
+            return None, None
+        try:
+            doc = json.load(open(tpath))
+            t = doc.get(args.workload)
+            kname = "stream_kernel" if args.path == "stream" else "lk_level_kernel"
+            if args.mode != "lk_float" or args.iters > 1:
+                kname += f"_{args.mode}_iters{args.iters}"
+            nbytes = t.get(kname) if isinstance(t, dict) else None
+            # (tools/pmc_run.py measures the default plan: two stages with the suggested frames per launch)
+            if args.path == "stream" and args.iters <= 1 and not (args.two_stage and args.batch == self.engine.suggest_stream_batch(self.w, self.h, self.levels, None, True, True)):
+                nbytes = None
+            src = {"file": "profiles/traffic_latest.json", "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_round.sh)",
+                   "measured_at_commit": doc.get("measured_at_commit"), "kernel_source_sha16": doc.get("kernel_source_sha16"),
+                   "note": "stored figure from the profiling run named here, not a measurement of this run"}
+            if doc.get("kernel_source_sha16") != kernel_source_hash():
+                src["stale"] = "the kernel sources have changed since the profile was taken: figure withheld"
+                nbytes = None
+            return nbytes, src
+        except Exception:
+            return None, None
+
+    def line(self, check_msg, extra):
+        args, driver, fps = self.args, self.driver, self.fps
+        w, h, levels, window = self.w, self.h, self.levels, self.window
+        ms = self.dt / args.steps * 1e3
+        stream_like = self.feed is not None
+        own_rows = None if driver is None else driver.plan.own
         # the timed launch is the fused LK kernel over ALL pyramid levels (one launch, ofx_lk_levels): algorithmic
         # bytes = 10 B x the pixels of every level this rank owns
         own_px = sum(level_px(w, h, levels, own_rows))
@@ -549,40 +919,35 @@ def main():
             lk_bytes = pair_bytes(w, h, levels, own_rows)
         pairs_per_launch = args.batch if stream_like else 1   # a stream tick carries args.batch frames / pairs
         lk_bytes *= pairs_per_launch
-        achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
+        k_avg_us, k_min_us, k_n = self.k_avg_us, self.k_min_us, self.k_n
         iters_pair = None
         if args.iters > 1:
             # refinement iterations: the roofline is that of the whole pair -- every launch of the second pass event-timed
-            # and tagged (ofx_session_timing_read_kind); bytes per SURVEY 8d: 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid
-            pair_alg = ((LK_BYTES_PER_PX + (args.iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * own_px +
-                        PYR_BYTES_PER_DST_PX * sum(level_px(w, h, levels, own_rows)[1:]))
-            us_pair = sum(v[0] * v[2] for v in kinds.values() if v[2]) / (roof_steps * fps)
+            # and tagged (ofx_session_timing_read_kind)
+            pair_alg = iters_pair_bytes(w, h, levels, args.iters, own_rows)
+            us_pair = sum(v[0] * v[2] for v in self.kinds.values() if v[2]) / (self.roof_steps * fps)
             iters_pair = {"algorithmic_bytes_per_pair": pair_alg, "kernel_us_per_pair": round(us_pair, 2),
-                          "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in kinds.items() if v[2]}}
-            lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, roof_steps
-            achieved = pair_alg / (us_pair * 1e-6) / 1e9 if us_pair else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                # per workload: {"stream_kernel": bytes, "lk_level_kernel": bytes} (tools/pmc_parse.py on separate --pmc passes)
-                t = json.load(open(tpath)).get(args.workload)
-                kname = "stream_kernel" if driver is None and args.path == "stream" else "lk_level_kernel"
-                if args.mode != "lk_float" or args.iters > 1:
-                    kname += f"_{args.mode}_iters{args.iters}"
-                traffic = t.get(kname) if isinstance(t, dict) and driver is None else None  # measured for whole frames only
-                # (tools/pmc_run.py measures the default plan: two stages with the suggested frames per launch)
-                if args.path == "stream" and args.iters <= 1 and not (args.two_stage and args.batch == engine.suggest_stream_batch(w, h, levels, None, True, True)):
-                    traffic = None
-            except Exception:
-                traffic = None
+                          "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in self.kinds.items() if v[2]}}
+            lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, self.roof_steps
+        achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
+        traffic, traffic_source = self.traffic()
         borrowed = args.borrow and ((driver is None and args.path == "stream") or
                                     (driver is not None and args.shard_corner == "local" and args.shard_halo != "exchange"))
+        frames_what = ("SURVEY 8d's smooth texture translating by (2,1) px per frame" if args.frames == "texture"
+                       else "uniform-random u8 frames (synth.random_pair, seeds 1 and 2)")
+        if stream_like:
+            stages = ((f"corner flows of the {pairs_per_launch} pair(s) those frames complete, on patch pyramids the corner blocks build | fused LK of all "
+                       f"levels of the {pairs_per_launch} pair(s) before") if args.two_stage and driver is None else
+                      (f"corner flows of the {pairs_per_launch} pair(s) before | fused LK of all levels of the {pairs_per_launch} pair(s) before those"))
+            kernel = (f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | {stages}; bytes per pair = "
+                      "10 B/px LK + 5 B/px pyramid)")
+        else:
+            kernel = "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"
         out = {
             "metric": "Mpix/s dense LK flow",
             "value": round(fps * w * h / (ms * 1e-3) / 1e6, 1),
             "unit": "Mpix/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": self.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 5),
             "frames_per_step": fps,
             "frames_per_s": round(fps * 1e3 / ms, 1),
@@ -593,19 +958,19 @@ def main():
             "data": "synthetic",
             "self_check": "skipped" if check_msg.startswith("SKIPPED") else "ok",
             "config": {
-                "untimed_clock_ramp_s": ramp_s, "warmup_steps_run": warmup_steps,
+                "untimed_clock_ramp_s": self.ramp_s, "warmup_steps_run": args.warmup,
                 "step": (f"one tick of the stream pipeline = one launch = {fps} frames (pairs): K = {args.steps} steps are {args.steps * fps} pairs"
                          if stream_like else "one frame pair"),
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
                             f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
-                            f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM",
+                            f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM; {frames_what}",
                 "frames": (("four resident device buffers, " + ("read in place (ofx_params.borrow_frames)" if driver is None and args.path == "plain"
                                                                    and args.borrow and w % 64 == 0 else "level 0 copied into the session per pair"))
-                           if not stream_like else f"a ring of {ring_n} distinct device buffers, " +
+                           if not stream_like else f"a ring of {self.ring_n} distinct device buffers, " +
                            (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {(2 if args.two_stage else 3) * args.batch} further submits)"
                             if borrowed else "level 0 copied into the session")),
                 "sharding": "none" if driver is None else (
-                    f"row blocks over {world} rank(s), halos recomputed from a wider level-0 halo; " +
+                    f"row blocks over {self.world} rank(s), halos recomputed from a wider level-0 halo; " +
                     ("every rank runs the one-launch stream pipeline on its block and forms the shift vectors from its own top-left "
                      "patch of the frame: no collective on the data path (DESIGN.md section 5)" if stream_like else
                      "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)"))
@@ -614,222 +979,50 @@ def main():
                 "self_check": check_msg,
             },
             "roofline": {
-                "bound": "hbm", "kernel": ((f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
-                            f"{pairs_per_launch} pair(s) those frames complete, on patch pyramids the corner blocks build | fused LK of all levels of the "
-                            f"{pairs_per_launch} pair(s) before; bytes per pair = 10 B/px LK + 5 B/px pyramid)" if args.two_stage and driver is None else
-                            f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | corner flows of the "
-                            f"{pairs_per_launch} pair(s) before | fused LK of all levels of the {pairs_per_launch} pair(s) before those; bytes per pair = "
-                            "10 B/px LK + 5 B/px pyramid)")
-                           if stream_like else
-                           "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"),
+                "bound": "hbm", "kernel": kernel,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "algorithmic_bytes_per_launch": lk_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),
                 "launches_timed": k_n, "timed_in": "second pass over the same steps with hipEventRecord around each launch on its stream",
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
             },
         }
         if iters_pair is not None:
             out["roofline"].update(iters_pair)
             out["roofline"]["kernel"] = (f"all launches of a pair with {args.iters} iterations (stream tick / LK, shift, {args.iters - 1} x warp, "
                                          f"{args.iters - 1} x accumulating LK); avg_launch_us = kernel time per pair")
-        if rccl_world is not None:
-            out["rccl_world"] = rccl_world   # sum of ones over the communicator: the ranks RCCL actually connected
+        if self.rccl_world is not None:
+            out["rccl_world"] = self.rccl_world   # sum of ones over the communicator: the ranks RCCL actually connected
         if not stream_like:
             # pair-at-a-time paths: every launch of a pair, event-timed in the same second pass
-            out["roofline"]["launches_per_pair_us"] = {k: round(v[0], 2) for k, v in kinds.items() if v[2]}
-        extra = {}
-        single = driver is None
-        if single and not args.no_extras and args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS:
-            # BASELINE.json's configs carry "N iters"; the reference has no iterations, so they run as the
-            # lk_iter extension here, next to the reference-defined line above (same process, same frames, plain path), with
-            # every launch of a pair event-timed: bytes per SURVEY 8d = 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid
-            it = BASELINE_ITERS[args.workload]
-            s2 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it)
-            s2.set_frame_device(d_frames[0]); s2.build_pyramid(); s2.swap()
-            def step2(i):
-                s2.set_frame_device(d_frames[(i + 1) % nframes]); s2.build_pyramid(); s2.run_flow(); s2.swap()
-            n2 = max(10, min(args.steps, 50))
-            for i in range(5):
-                step2(i)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(n2):
-                step2(5 + i)
-            torch.cuda.synchronize()
-            ms2 = (time.perf_counter() - t0) / n2 * 1e3
-            s2.timing(n2 * (2 * it + 3))
-            for i in range(n2):
-                step2(5 + n2 + i)
-            torch.cuda.synchronize()
-            kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
-            s2.timing(0)
-            px_all = sum(level_px(w, h, levels))
-            px_shift = sum(level_px(w, h, levels)[:-1])
-            per_kind_bytes = {"lk": LK_BYTES_PER_PX * px_all, "lk_acc": LK_ACC_BYTES_PER_PX * px_all, "warp": WARP_BYTES_PER_PX * px_all,
-                              "shift": 2 * px_shift, "pyramid": PYR_BYTES_PER_DST_PX * sum(level_px(w, h, levels)[1:])}
-            launches = {}
-            for k, (avg, mn, cnt) in kk.items():
-                if cnt:
-                    launches[k] = {"avg_us": round(avg, 2), "per_pair": cnt // n2}
-                    if k in per_kind_bytes:
-                        launches[k]["algorithmic_bytes"] = per_kind_bytes[k]
-                        launches[k]["frac"] = round(per_kind_bytes[k] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-            pair_alg = (LK_BYTES_PER_PX + (it - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * px_all + per_kind_bytes["pyramid"]
-            kernel_us = sum(v[0] * (v[2] // n2) for v in kk.values() if v[2])
-            extra["baseline_config_with_iters"] = {
-                "workload": f"{w}x{h}, {levels} levels, {window}x{window}, iters={it} (extension lk_iter: bilinear-warp refinement)",
-                "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms2, 5),
-                "frames_per_s": round(1e3 / ms2, 1), "steps": n2,
-                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_pair": pair_alg,
-                             "kernel_us_per_pair": round(kernel_us, 2), "achieved": round(pair_alg / (kernel_us * 1e-6) / 1e9, 1),
-                             "frac": round(pair_alg / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "launches": launches,
-                             "timed_in": "second pass, hipEventRecord around every launch of the pair"}}
-            s2.close()
-            # the same configuration through the stream pipeline: the tick's LK stage is iteration 1 of its B pairs, every
-            # further iteration one warp + one accumulating LK launch over all levels of all B pairs (taller strips, 2 + 2 *
-            # (iters - 1) launches per B pairs instead of 3 + 2 * iters per pair); frames read in place like the headline's
-            b9 = 4 if 4 * levels <= 80 else 2
-            s9 = engine.Session(w, h, levels, window, args.mode, device=local_rank, iters=it, stream_batch=b9, borrow_frames=args.borrow)
-            s9.stream_begin()
-            fd9 = StreamFeed(s9.stream_submit_frames, d_ring, b9)
-            for _ in range(4 * b9):
-                fd9.step()
-            torch.cuda.synchronize()
-            n9 = max(4 * b9, min(args.steps, 48) // b9 * b9)
-            t0 = time.perf_counter()
-            for _ in range(n9):
-                fd9.step()
-            torch.cuda.synchronize()
-            ms9 = (time.perf_counter() - t0) / n9 * 1e3
-            s9.timing((n9 // b9) * (2 * it + 3))
-            for _ in range(n9):
-                fd9.step()
-            torch.cuda.synchronize()
-            k9 = {k: s9.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
-            s9.timing(0)
-            s9.close()
-            us9 = sum(v[0] * v[2] for v in k9.values() if v[2]) / n9            # kernel time per pair
-            pair_alg9 = pair_alg                                                # same algorithmic bytes per pair
-            streamed = {
-                "workload": f"as above through the stream pipeline, {b9} pairs per launch, frames " + ("read in place" if args.borrow else "copied"),
-                "value": round(w * h / (ms9 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms9, 5), "steps": n9,
-                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_pair": pair_alg9,
-                             "kernel_us_per_pair": round(us9, 2), "achieved": round(pair_alg9 / (us9 * 1e-6) / 1e9, 1),
-                             "frac": round(pair_alg9 / (us9 * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                             "launches": {k: {"avg_us": round(v[0], 2), "per_tick": v[2] // (n9 // b9)} for k, v in k9.items() if v[2]}}}
-            extra["baseline_config_with_iters"]["streamed"] = streamed
-            if args.path == "stream" and args.borrow:
-                # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
-                # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
-                b3 = engine.suggest_stream_batch(w, h, levels, None, False)
-                r3 = stream_leg((w, h, levels, window), args.mode, b3, False, d_ring[:16] if len(d_ring) > 16 else d_ring, args.steps)
-                r3["workload"] = f"as value, but the session copies level 0 of every frame ({b3} frames per launch)"
-                extra["stream_with_copied_frames"] = r3
-                # cache-cold inputs: the ring is long enough that neither the frames nor the session's image sets survive in the
-                # 256 MB Infinity Cache between their uses (ring of 32 4K buffers = 265 MB on its own), i.e. every image row the
-                # level kernel reads comes from HBM -- what a pipeline fed from a large surface pool sees
-                cold_n = max(32, 2 * ring_n)
-                if w * h * cold_n < 40e9:
-                    cold_ring = make_ring(d_frames, cold_n)
-                    r6 = stream_leg((w, h, levels, window), args.mode, args.batch, True, cold_ring, args.steps)
-                    r6["workload"] = (f"as value, frames read in place from a ring of {cold_n} distinct buffers ({w * h * cold_n / 1e6:.0f} MB: nothing "
-                                      "survives in the Infinity Cache between uses)")
-                    extra["cold_inputs"] = r6
-                    del cold_ring
-            if args.path == "stream":
-                # the same pipeline with the solve in its <= 1 ulp(float) formulation (OFX_MODE_LK_FLOAT_FAST: SURVEY 8c's stated
-                # tolerance for the solve, identical NaN / Inf positions; window sums, shift and pyramid stay bit-exact)
-                r8 = stream_leg((w, h, levels, window), "lk_float_fast", args.batch, args.borrow, d_ring, args.steps)
-                r8["workload"] = "as value, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
-                extra["fast_solve"] = r8
-                # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
-                bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow, args.two_stage)
-                r7 = stream_leg((w, h, levels, window), "compat_cpu", bc, args.borrow, d_ring if bc == args.batch else make_ring(d_frames, ring_size(bc)), args.steps)
-                r7["workload"] = f"as value, mode compat_cpu (OptFlowCPU.cpp:312-399 bug for bug; stream path, {bc} frames per launch)"
-                extra["compat_cpu"] = r7
-            if args.path == "stream" and args.workload == "4k":
-                # the metric names 1080p pairs next to 4K ones (BASELINE.json): the same pipeline on the 1080p configuration
-                wl5 = WORKLOADS["1080p"]
-                b5 = engine.suggest_stream_batch(*wl5[:3], None, True, args.two_stage)  # (the leg reads its frames in place)
-                f5 = make_ring([torch.from_numpy(synth.smooth_pair(wl5[0], wl5[1], 2.0 * i * mx, 1.0 * i * my)[1]).cuda() for i in range(nframes)],
-                               ring_size(b5))
-                r5 = stream_leg(wl5, args.mode, b5, True, f5, args.steps)
-                r5["workload"] = f"{wl5[0]}x{wl5[1]} pair, {wl5[2]}-level pyramid, {wl5[3]}x{wl5[3]} window, iters=1, stream path, {b5} frames per launch"
-                extra["workload_1080p"] = r5
-                del f5
-            # API-compat timing: host pointers through the reference's own call surface -- gpu::gauss_pyramid for both
-            # frames + gpu::calc_opt_flow per level (OptFlowGpu.cu:1909; window 19 is hard-coded there) -- PCIe included
-            from cuda_optical_flow_2_amd.compat import GpuCompat
-            gc = GpuCompat()
-            api = {}
-            for nm in ("1080p", "4k"):
-                wa, ha, la, _ = WORKLOADS[nm]
-                pa, na = synth.smooth_pair(wa, ha)
-                p3, n3 = synth.to_3ch(pa), synth.to_3ch(na)
-                gc.flow_pair(p3, n3, la)
-                reps = 3
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    gc.flow_pair(p3, n3, la)
-                dta = (time.perf_counter() - t0) / reps
-                api[nm] = {"value": round(wa * ha / dta / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(dta * 1e3, 2),
-                           "workload": f"{wa}x{ha}, {la} levels, window 19 (the reference's GPU constant), 3-channel host images in, "
-                                       "host flow pyramid out, both pyramids rebuilt per pair as gpu::gauss_pyramid's signature demands"}
-            extra["api_compat"] = api
-            # the front end of main.cu's frame (main.cu:232-240, in front of the pyramid): grayscale + the 9x9 bilateral
-            # pre-filter (sigma 2 / 10), device-resident, 3-channel images as the reference passes them.  Bytes per pixel
-            # (SURVEY 8d): grayscale 3 read + 3 written, bilateral 3 (src) + 3 (gray) read + 3 written.  The bilateral filter
-            # is bit-exact fp64 arithmetic in the reference's tap order (81 taps x ~16 double operations per pixel): it is
-            # compute-bound by that definition, the HBM fraction says how far.
-            from cuda_optical_flow_2_amd import lib as _l
-            L_ = _l.load()
-            fe = {}
-            for nm in ("1080p", "4k"):
-                wa, ha = WORKLOADS[nm][:2]
-                img = torch.randint(0, 256, (ha, wa, 3), dtype=torch.uint8, device="cuda")
-                gray, filt = torch.empty_like(img), torch.empty_like(img)
-                st_ = torch.cuda.current_stream().cuda_stream
-
-                def timed(fn, reps):
-                    fn(); torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(reps):
-                        fn()
-                    e1.record(); torch.cuda.synchronize()
-                    return e0.elapsed_time(e1) / reps * 1e3
-                t_g = timed(lambda: _l.check(L_.ofx_grayscale_avg_3ch(img.data_ptr(), gray.data_ptr(), wa, ha, st_), "grayscale"), 20)
-                t_b = timed(lambda: _l.check(L_.ofx_bilateral_3ch(gray.data_ptr(), gray.data_ptr(), filt.data_ptr(), wa, ha, 9, 9, 2.0, 10.0, st_), "bilateral"), 5)
-                fe[nm] = {"grayscale_us": round(t_g, 1), "grayscale_frac": round(6 * wa * ha / (t_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                          "bilateral_9x9_us": round(t_b, 1), "bilateral_frac": round(9 * wa * ha / (t_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                          "value": round(wa * ha / ((t_g + t_b) * 1e-6) / 1e6, 1), "unit": "Mpix/s"}
-                del img, gray, filt
-            extra["frontend"] = fe
-        if dt_indep is not None:
-            ms4 = dt_indep * 1e3
-            extra["independent_pairs_per_rank"] = {
-                "workload": f"every one of the {world} rank(s) runs the unsharded stream pipeline on its own frame pairs (no sharding, no "
-                            "communication): aggregate pairs/s, weak scaling, latency per pair as on one GPU",
-                "value": round(world * w * h / (ms4 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step_per_rank": round(ms4, 5),
-                "frames_per_rank": n4}
-        if dt_exch is not None:
-            if dt_exch[0] is None:
-                extra["halo_exchange"] = {"skipped": dt_exch[2]}
-            else:
-                ms5 = dt_exch[0] / dt_exch[1] * 1e3
-                extra["halo_exchange"] = {
-                    "workload": f"north_star's literal formulation over {world} rank(s): own rows only, halo rows of every pyramid level exchanged "
-                                "with the neighbouring ranks (batched RCCL send/recv per level), shift vectors by RCCL broadcast; pair at a time",
-                    "value": round(w * h / (ms5 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(ms5, 5), "steps": dt_exch[1],
-                    "status_word": dt_exch[2]}
+            out["roofline"]["launches_per_pair_us"] = {k: round(v[0], 2) for k, v in self.kinds.items() if v[2]}
         if extra:
             out["extra"] = extra
-        if driver is None and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, w, h, levels, window)
+        return out
+
+
+def main():
+    args = parse_args()
+    plan_stream(args)
+    run = Run(args)
+    run.build_headline()
+    run.time_headline()
+    # (timing experiments with ablated kernels, OFX_BUILD_DEFS=-DOFX_X_*: their results are wrong by construction)
+    check_msg = "SKIPPED (OFX_BENCH_SKIP_CHECK)" if os.environ.get("OFX_BENCH_SKIP_CHECK") == "1" else run.self_check()
+    if run.distributed:
+        run.dist.barrier()
+    extra = {}
+    if run.driver is not None:
+        extra.update(run.extras_distributed())
+    if run.rank == 0:
+        if run.driver is None and not args.no_extras:
+            extra.update(run.extras_single_gpu())
+        out = run.line(check_msg, extra)
+        if run.driver is None and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, run.w, run.h, run.levels, run.window)
         print(json.dumps(out), flush=True)
-    if distributed:
-        dist.destroy_process_group()
+    if run.distributed:
+        run.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

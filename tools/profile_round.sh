@@ -1,8 +1,9 @@
 # Round evidence for profiles/: rocprofv3 kernel stats of the bench command (stream and plain path, iters = 5, compat_cpu) and
 # HBM traffic per launch from separate --pmc passes (FETCH_SIZE / WRITE_SIZE; never combined with tracing).
-#   gpurun -- 'bash tools/profile_round.sh r02'      then copy gpurun_out/prof_<tag>/summary/* into profiles/
+#   gpurun -- 'bash tools/profile_round.sh r03'      then copy gpurun_out/prof_<tag>/summary/* into profiles/ and stamp the commit:
+#   python tools/stamp_traffic.py   (the GPU box has no .git)
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
@@ -19,6 +20,17 @@ stats plain --path plain
 stats iters5 --iters 5 --steps 200
 stats iters5_plain --iters 5 --steps 200 --path plain
 stats compat_cpu --mode compat_cpu
+stats random --frames random
+# the other BASELINE configurations as written: file names say which
+stats8() { n=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
+  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench_${n}_kernel_stats.csv
+  echo "== $n"; head -4 "$f"
+}
+stats8 8k --workload 8k --steps 200
+stats8 8k_iters10 --workload 8k --iters 10 --steps 12 --warmup 4
+stats8 1080p --workload 1080p --steps 500
+stats8 1080p_iters5 --workload 1080p --iters 5 --steps 50 --warmup 8
 pmc() { # name, kernel substring, skip, pmc_run args...
   n=$1; k=$2; skip=$3; shift 3
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -36,7 +48,10 @@ python - $O/summary/${TAG}_traffic_pmc.jsonl > $O/summary/traffic_latest.json <<
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
 names = ["stream_kernel", "lk_level_kernel", "stream_kernel_compat_cpu_iters1", "lk_level_kernel_lk_float_iters5", "warp_u8_kernel_lk_float_iters5"]
+sys.path.insert(0, ".")
+import bench
 out = {"4k": {n: r.get("bytes") for n, r in zip(names, rows)},
+       "kernel_source_sha16": bench.kernel_source_hash(), "measured_at_commit": None,
        "note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc in separate passes (tools/profile_round.sh, tools/pmc_parse.py); "
                "lk_level_kernel_lk_float_iters5 is the mean over the writing launch and the four accumulating ones of a pair"}
 print(json.dumps(out, indent=1))
