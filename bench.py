@@ -690,25 +690,30 @@ class Run:
                                                    avg_launch_us=round(kk["pyramid"][0], 2))}
 
     def leg_api_compat(self):
-        """API-compat timing (SURVEY 8d): host pointers through the reference's own call surface -- gpu::gauss_pyramid for both
-        frames + gpu::calc_opt_flow per level (OptFlowGpu.cu:1909; window 19 is hard-coded there) -- PCIe included"""
+        """API-compat timing: host pointers through the reference's own call surface, as main.cu's frame loop drives
+        it -- per frame: copy into level 0 (main.cu:246), gpu::gauss_pyramid in place (:250), gpu::calc_opt_flow per level (:256-262;
+        window 19 is hard-coded there), swap (:270-272); buffers allocated once, as alloc_pyramid does (:203-205) -- PCIe included.
+        One pyramid per frame, not two: the previous frame's is reused, exactly as the reference does."""
         from cuda_optical_flow_2_amd.compat import GpuCompat
 
         gc = GpuCompat()
         api = {}
         for nm in ("1080p", "4k"):
             wa, ha, la, _ = WORKLOADS[nm]
-            pa, na = self.synth.smooth_pair(wa, ha)
-            p3, n3 = self.synth.to_3ch(pa), self.synth.to_3ch(na)
-            gc.flow_pair(p3, n3, la)
-            reps = 3
+            fr = [self.synth.to_3ch(f) for f in self.host_frames(wa, ha)]
+            loop = gc.frame_loop(wa, ha, la)
+            loop.first(fr[0])
+            loop.step(fr[1])
+            reps = 4
             t0 = time.perf_counter()
-            for _ in range(reps):
-                gc.flow_pair(p3, n3, la)
+            for i in range(reps):
+                loop.step(fr[(i + 2) % len(fr)])
             dta = (time.perf_counter() - t0) / reps
-            api[nm] = {"value": round(wa * ha / dta / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(dta * 1e3, 2),
-                       "workload": f"{wa}x{ha}, {la} levels, window 19 (the reference's GPU constant), 3-channel host images in, "
-                                   "host flow pyramid out, both pyramids rebuilt per pair as gpu::gauss_pyramid's signature demands"}
+            api[nm] = {"value": round(wa * ha / dta / 1e6, 1), "unit": "Mpix/s", "ms_per_frame": round(dta * 1e3, 2),
+                       "workload": f"{wa}x{ha}, {la} levels, window 19 (the reference's GPU constant), 3-channel host frames in, host flow "
+                                   "pyramid out, main.cu's loop: one pyramid + every level per frame, host buffers reused"}
+        from cuda_optical_flow_2_amd import lib as _l
+        api["staging_threads"] = _l.load().ofx_stage_threads()
         return api
 
     def leg_frontend(self):

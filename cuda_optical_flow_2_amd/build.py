@@ -21,7 +21,7 @@ ARCH = "gfx950"
 
 SOURCES = ["lk_inst_stream_f.hip", "lk_inst_stream_fast.hip", "lk_inst_stream_c.hip", "lk_inst_levels_f.hip", "lk_inst_levels_fast.hip",
            "lk_inst_levels_c.hip", "lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp",
-           "compat_gpu.cpp", "compat_cpu.cpp"]
+           "compat_gpu.cpp", "compat_cpu.cpp", "compat_stage.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
 # buys nothing on gfx950 (packed fp32 issues at half the rate of scalar fp32; tools/ubench/valu_rates.hip)
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if force or jobs or _stale(OUT, objs):
-        cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        cmd = [cc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)

@@ -183,6 +183,13 @@ class GpuCompat:
             self.calc_opt_flow(pp[k], npyr[k], flow, k, levels)
         return flow, pp, npyr
 
+    def frame_loop(self, w, h, levels):
+        """main.cu's frame loop with ITS buffer discipline: the two image pyramids and the flow pyramid are allocated once
+        (main.cu:203-205, alloc_pyramid) and reused for every frame; a frame is copied into level 0 of its pyramid (:246), the
+        pyramid is built in place (:250), calc_opt_flow runs coarse to fine (:256-262), and the pyramids are swapped (:270-272).
+        (flow_pair above allocates fresh numpy arrays per call: timing it measures first-touch page faults, not the library.)"""
+        return _FrameLoop(self, w, h, levels)
+
 
     def conv_1d_3ch(self, src3):
         src3 = _c(src3, np.uint8).copy()
@@ -191,6 +198,39 @@ class GpuCompat:
         self._f("conv_1d_3ch")(_p(src3, _u8p), w, h, _p(d, _u8p))
         self._done("conv_1d_3ch")
         return d
+
+
+class _FrameLoop:
+    def __init__(self, gc, w, h, levels):
+        self.gc, self.w, self.h, self.levels = gc, w, h, levels
+        mk = lambda: [np.zeros((h >> k, w >> k, 3), np.uint8) for k in range(levels)]
+        self.prev, self.cur = mk(), mk()
+        self.flow = [np.zeros((h >> k, w >> k, 2), np.float32) for k in range(levels)]
+        for a in self.prev + self.cur + self.flow:
+            a.fill(0)   # touch every page once, as a running frame loop has
+        self._gp, self._cof = gc._f("gauss_pyramid"), gc._f("calc_opt_flow")
+        self._mask = _p(gc.GAUS_KERNEL_3x3, _f32p)
+        self.have_prev = False
+
+    def _pyramid(self, pyr, frame3):
+        np.copyto(pyr[0], frame3)                                                     # main.cu:246
+        self._gp(_ptrs(pyr, C.c_uint8), self.w, self.h, self.levels, self._mask, 3, 3)  # main.cu:250
+        self.gc._done("gauss_pyramid")
+
+    def first(self, frame3):
+        self._pyramid(self.prev, frame3)                                              # main.cu:203-209
+        self.have_prev = True
+
+    def step(self, frame3):
+        """one frame: its pyramid, every flow level against the previous frame's pyramid, swap; returns the flow pyramid (reused)"""
+        assert self.have_prev
+        self._pyramid(self.cur, frame3)
+        fl = _ptrs(self.flow, C.c_float)
+        for k in range(self.levels - 1, -1, -1):                                      # main.cu:256-262
+            self._cof(_p(self.prev[k], _u8p), _p(self.cur[k], _u8p), self.w >> k, self.h >> k, fl, k, self.levels)
+            self.gc._done("calc_opt_flow")
+        self.prev, self.cur = self.cur, self.prev                                     # main.cu:270-272
+        return self.flow
 
 
 class UtilsCompat:

@@ -4,11 +4,12 @@
 // SURVEY 3.2).  Here a wrapper call carves its buffers out of a per-thread arena that is kept between calls: in the steady
 // state of a frame loop (the same sizes every frame) no wrapper allocates at all.  A call that needs more than the arena
 // holds takes extra blocks for its own duration; when it ends the arena is re-sized to what that call used, so the next
-// one fits.  Blocking copies on the null stream order everything, as the reference's cudaMemcpy does.
+// one fits.  The copies are synchronous, as the reference's cudaMemcpy is (large ones are staged by several threads: compat_stage.cpp).
 #pragma once
 
 #include <vector>
 
+#include "compat_stage.h"
 #include "ofx_internal.h"
 
 namespace ofx_compat {
@@ -17,9 +18,13 @@ struct Arena {
     void *base = nullptr;
     size_t cap = 0;
     int device = -1;
+    int live = 0; // Scratch objects alive on this thread: they all carve from `base`, so there may be one at a time
     ~Arena()
     {
-        if (base) (void)hipFree(base); // thread exit; may run after the runtime has shut down, errors ignored
+        // thread exit.  On the main thread this can run after the HIP runtime has shut down: then the block is the driver's
+        // to reclaim with the process, and no HIP call is made.
+        int dev = 0;
+        if (base && hipGetDevice(&dev) == hipSuccess) (void)hipFree(base);
     }
 };
 
@@ -41,11 +46,16 @@ class Scratch {
             a.cap = 0;
         }
         a.device = dev;
+        if (a.live++ > 0) { // a wrapper that opened a second Scratch would be handed the first one's memory again
+            ofx_set_error("compat scratch: nested use on one thread (a wrapper called from inside a wrapper)");
+            rc_ = OFX_E_STATE;
+        }
     }
     ~Scratch()
     {
         for (void *p : extra_) (void)hipFree(p);
         Arena &a = arena();
+        --a.live;
         if (need_ > a.cap) { // grow once, to what this call used in total (25 % slack for slightly larger frames)
             if (a.base) (void)hipFree(a.base);
             a.base = nullptr;
@@ -99,11 +109,9 @@ class Scratch {
   private:
     void copy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
     {
-        const hipError_t e = hipMemcpy(dst, src, bytes, kind); // blocking, ordered after the null-stream kernels
-        if (e != hipSuccess) {
-            ofx_set_error("hipMemcpy(%zu bytes): %s", bytes, hipGetErrorString(e));
-            rc_ = OFX_E_HIP;
-        }
+        // chunked through pinned bounce buffers by a few threads (compat_stage.cpp); synchronous like the hipMemcpy of the reference
+        const int rc = kind == hipMemcpyHostToDevice ? stage_h2d(dst, src, bytes) : stage_d2h(dst, src, bytes);
+        if (rc != OFX_OK) rc_ = rc;
     }
     std::vector<void *> extra_;
     size_t used_ = 0, need_ = 0;

@@ -300,6 +300,158 @@ __device__ __forceinline__ void hbox4(const int (&a)[4], int (&out)[4])
     }
 }
 
+// ---- the five box sums of a step in lockstep -----------------------------------------------------------------------------------
+// hbox4 above handles one quantity: a chain of DPP operations, each fenced by an empty asm so that hipcc's DPP combiner cannot
+// fold it wrongly (lane_shift_right).  Fenced, the chain's instructions stay in source order, every one reading the register the
+// one before has just written -- and a DPP operand needs two wait states after the VALU write of its register: ~30 s_nop per
+// row step (a tenth of the march's scalar instructions).  The five quantities of a step are independent, so hbox4x5 walks the
+// same chain for all five at once, stage by stage: between two dependent instructions of one quantity lie the four of the others.
+// Same operations, same operands, same results.
+template <int K>
+__device__ __forceinline__ void lane_from5(const int (&x)[5], int (&r)[5])
+{
+    if constexpr (K == 0) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) r[n] = x[n];
+    } else {
+        int t[5];
+#pragma unroll
+        for (int n = 0; n < 5; ++n) t[n] = K > 0 ? lane_shift_left(x[n]) : lane_shift_right(x[n]);
+        lane_from5<(K > 0 ? K - 1 : K + 1)>(t, r);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void add_from5(int (&acc)[5], const int (&x)[5])
+{
+    if constexpr (D == 0) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) acc[n] += x[n];
+    } else {
+        int near[5];
+        lane_from5<(D > 0 ? D - 1 : D + 1)>(x, near); // all but the last lane step: fenced moves
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            int r = acc[n] + __builtin_amdgcn_update_dpp(0, near[n], D > 0 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+            asm volatile("" : "+v"(r));
+            acc[n] = r;
+        }
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void column5(const int (&a)[5][4], int (&x)[5])
+{
+#pragma unroll
+    for (int n = 0; n < 5; ++n) x[n] = a[n][C];
+}
+
+template <int R, int I, int D>
+__device__ __forceinline__ void hbox_right5(const int (&q)[5][4], int (&acc)[5])
+{
+    constexpr int hi = I + R;
+    if constexpr (hi < 4 * D) {
+        return;
+    } else if constexpr (hi >= 4 * D + 3) {
+        int x[5];
+        column5<3>(q, x);
+        add_from5<D>(acc, x);
+        hbox_right5<R, I, D + 1>(q, acc);
+    } else {
+        int x[5];
+        column5<hi - 4 * D>(q, x);
+        add_from5<D>(acc, x);
+    }
+}
+
+template <int R, int I, int D>
+__device__ __forceinline__ void hbox_left5(const int (&s)[5][4], int (&acc)[5])
+{
+    constexpr int lo = I - R;
+    if constexpr (lo > -4 * D + 3) {
+        return;
+    } else if constexpr (lo <= -4 * D) {
+        int x[5];
+        column5<0>(s, x);
+        add_from5<-D>(acc, x);
+        hbox_left5<R, I, D + 1>(s, acc);
+    } else {
+        int x[5];
+        column5<lo + 4 * D>(s, x);
+        add_from5<-D>(acc, x);
+    }
+}
+
+template <int R, int I>
+__device__ __forceinline__ void hbox_one5(const int (&q)[5][4], const int (&s)[5][4], int (&out)[5])
+{
+    constexpr int lo = I - R, hi = I + R;
+    constexpr int olo = lo > 0 ? lo : 0, ohi = hi < 3 ? hi : 3;
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        if constexpr (olo == 0) out[n] = q[n][ohi];
+        else if constexpr (ohi == 3) out[n] = s[n][olo];
+        else out[n] = q[n][ohi] - q[n][olo - 1];
+    }
+    hbox_right5<R, I, 1>(q, out);
+    hbox_left5<R, I, 1>(s, out);
+}
+
+// r = (column C's value) - y for the five quantities (col_minus, staged)
+template <int C>
+__device__ __forceinline__ void col_minus5(const int (&a)[5][4], const int (&y)[5], int (&r)[5])
+{
+    if constexpr (C >= 0 && C <= 3) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) r[n] = a[n][C] - y[n];
+    } else {
+        constexpr int idx = ((C % 4) + 4) % 4;
+        constexpr int dist = (C - idx) / 4; // lanes away: > 0 to the right
+        int x[5], near[5];
+        column5<idx>(a, x);
+        lane_from5<(dist > 0 ? dist - 1 : dist + 1)>(x, near);
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            int t = __builtin_amdgcn_update_dpp(0, near[n], dist > 0 ? 0x130 /* wave_shl:1 */ : 0x138 /* wave_shr:1 */, 0xf, 0xf, true) - y[n];
+            asm volatile("" : "+v"(t));
+            r[n] = t;
+        }
+    }
+}
+
+// a[n][j]: vertical sum of quantity n in this lane's column j; out[n][j]: its box sum over columns [c - R, c + R]
+template <int R>
+__device__ __forceinline__ void hbox4x5(const int (&a)[5][4], int (&out)[5][4])
+{
+    int q[5][4], s[5][4];
+#pragma unroll
+    for (int n = 0; n < 5; ++n) {
+        q[n][0] = a[n][0];
+        q[n][1] = q[n][0] + a[n][1];
+        q[n][2] = q[n][1] + a[n][2];
+        q[n][3] = q[n][2] + a[n][3];
+        s[n][3] = a[n][3];
+        s[n][2] = s[n][3] + a[n][2];
+        s[n][1] = s[n][2] + a[n][1];
+        s[n][0] = q[n][3];
+    }
+    int o0[5], o1[5], o2[5], o3[5];
+    hbox_one5<R, 0>(q, s, o0);
+    hbox_one5<R, 3>(q, s, o3);
+    if constexpr (OFX_LK_HBOX_SLIDE && R <= OFX_LK_HBOX_SLIDE_MAX_R) {
+        int t[5];
+        col_minus5<0 - R>(a, o0, t);
+        col_minus5<1 + R>(a, t, o1);
+        col_minus5<3 + R>(a, o3, t);
+        col_minus5<2 - R>(a, t, o2);
+    } else {
+        hbox_one5<R, 1>(q, s, o1);
+        hbox_one5<R, 2>(q, s, o2);
+    }
+#pragma unroll
+    for (int n = 0; n < 5; ++n) out[n][0] = o0[n], out[n][1] = o1[n], out[n][2] = o2[n], out[n][3] = o3[n];
+}
+
 // geometry of a wave tile for radius R (also used by the host)
 template <int R>
 struct TileGeom {
@@ -716,6 +868,20 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
         const bool folded = H > 0 && s < H;   // high halves: the entering row y_first + s
         const int yh = folded ? y_first + s : yo;
 
+#if defined(OFX_X_EXTRA_SALU) || defined(OFX_X_EXTRA_VALU) // sensitivity experiments: N more scalar / vector instructions per row step
+        {
+#ifdef OFX_X_EXTRA_SALU
+            int sx = s;
+#pragma unroll
+            for (int e = 0; e < OFX_X_EXTRA_SALU; ++e) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx));
+#endif
+#ifdef OFX_X_EXTRA_VALU
+            int vx = lane;
+#pragma unroll
+            for (int e = 0; e < OFX_X_EXTRA_VALU; ++e) asm volatile("v_add_u32 %0, %0, %0" : "+v"(vx));
+#endif
+        }
+#endif
         // Issue the loads of the rows the next step adds (yy + 2 and the high stream's).  They are finished (mask / permute /
         // unpack) at the end of this step, before its flow stores: gfx9 counts loads and stores in one vmcnt and only orders
         // returns within a type, so a wait for a load that has younger stores outstanding is a wait for those stores too.
@@ -882,6 +1048,10 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
 }
 
 
+} // namespace ofx_dev
+#include "lk_body_buf.h" // lk_wave_buf: the same march on buffer resources (a fifth of the scalar instructions)
+namespace ofx_dev {
+
 // One wave of the fused level kernel: picks the variant for its tile (wave-uniform: two complete copies of the march, nothing
 // merges after them).
 template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false>
@@ -896,6 +1066,14 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
     }
     const int tile = (wave - T.first_block[level]) % T.lv[level].tiles_x;
     const int cb0 = tile * TileGeom<R>::OUT_W - TileGeom<R>::LO_LANE * 4;
+    if constexpr (OFX_LK_BUFFER_PATH && !SUMS && !MAY_ACC) { // (the host keeps levels of 2 GB and more out of such launches)
+#if OFX_LK_INTERIOR_VARIANT
+        if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true>(T, wave, lane, xlds);
+        else
+#endif
+            lk_wave_buf<R, MODE, FAST, false>(T, wave, lane, xlds);
+        return;
+    }
 #if OFX_LK_INTERIOR_VARIANT
     if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_impl<R, MODE, SUMS, MAY_ACC, FAST, true>(T, wave, lane, xlds);
     else

@@ -1,0 +1,347 @@
+// The LK march on buffer resources: the scalar diet of round 3.  Included by lk_body.h (which holds the shared pieces: packed
+// rows, derivatives, accumulation, box sums, the LDS exchange) -- not a stand-alone header.
+//
+// profiles/r03_ablation.txt: adding 40 scalar instructions to a row step lengthens the stream launch by 8.5 us -- a SIMD pays
+// ~1.35 cycles for every scalar instruction of its waves, and lk_wave_impl spends ~220 of them per step (a fifth of the launch),
+// three quarters on row addresses (a 64-bit multiply-add per load), on wave-uniform tests with their branches ("is this row
+// inside the image / the strip / the buffer") and on exec masks around the stores.  This form of the march hands that work to
+// the memory pipeline's own range check:
+//   * the planes and the flow are addressed through BUFFER RESOURCES (base + extent in four SGPRs): a load is
+//     buffer_load_dword v, lane offset, rsrc, row offset -- the row offset is one 32-bit scalar, no 64-bit arithmetic;
+//   * a row that does not exist gets the offset kOob (0x80000000): the load then lies outside the resource's extent and
+//     returns 0, exactly what the zero border wants -- no branch; the rows of `next` come from a 64-entry table of offsets
+//     (the shifted row, or kOob), so the reference's row map costs one v_readlane;
+//   * a lane that must not store gets the lane offset kOob: the store is dropped by the same check -- no exec mask.
+// tools/ubench/buffer_ops.hip checks these behaviours on the device (unaligned dword, marker row, dropped stores).
+// The arithmetic, the LDS exchange, the packed registers and the order of loads and stores are those of lk_wave_impl; results
+// are bit-identical (the same tests run on both; OFX_LK_BUFFER_PATH=0 builds the old form everywhere).  The old form stays
+// for the inspection variant (SUMS) and for accumulating launches (MAY_ACC); the host keeps levels of 2 GB and more out of
+// launches that use this one (lk_launch.h).
+#pragma once
+
+namespace ofx_dev {
+
+#ifndef OFX_LK_BUFFER_PATH
+#define OFX_LK_BUFFER_PATH 1
+#endif
+#ifndef OFX_LK_HBOX_LOCKSTEP
+#define OFX_LK_HBOX_LOCKSTEP 1
+#endif
+constexpr int kOob = (int)0x80000000;
+#if defined(OFX_LK_STORE_AUX) // (experiments: other cache-policy bits of the flow stores -- bit 0 sc0, bit 1 nt, bit 4 sc1)
+#elif defined(OFX_X_TINYSTORE)
+#define OFX_LK_STORE_AUX 0 // (cached)
+#else
+#define OFX_LK_STORE_AUX (OFX_LK_NT_STORES ? 2 : 0) // nt: streaming stores (see "the flow stores" in lk_body.h)
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00027000);
+}
+
+template <int R, int MODE, bool FAST, bool INTERIOR>
+__device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane, uint8_t *xlds)
+{
+    using G = TileGeom<R>;
+    constexpr int NS = 2 * R + 1;
+
+    if (wave >= T.first_block[T.n]) return;
+    int level = 0, hi = T.n;
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (wave >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
+    LkArgs A = T.lv[level];
+    pin_scalar(A.w);
+    pin_scalar(A.h);
+    pin_scalar(A.pitch);
+    pin_scalar(A.row0);
+    pin_scalar(A.row_end);
+    pin_scalar(A.flow_row0);
+    pin_scalar(A.min_det);
+    const SolveOpts sopt{A.min_det};
+    const int block = wave - T.first_block[level];
+    const int tile = block % A.tiles_x;
+    const int strip = block / A.tiles_x;
+    const int cb = tile * G::OUT_W - G::LO_LANE * 4 + 4 * lane; // first of this lane's 4 image columns
+    const int ys = A.out_y0 + strip * A.strip_h;
+    const int ye = min(ys + A.strip_h, A.out_y1);
+
+    // the planes (both have the level's geometry) and the flow as buffer resources
+    const int plane_bytes = (A.row_end - A.row0) * A.pitch;
+    const __amdgpu_buffer_rsrc_t rs_prev = make_rsrc(A.prev, plane_bytes), rs_next = make_rsrc(A.next, plane_bytes);
+    const __amdgpu_buffer_rsrc_t rs_flow = make_rsrc(A.flow, (A.out_y1 - A.flow_row0) * A.w * 8);
+
+    // column validity: bytes outside [0,w) read as zero, derivatives there are zero
+    const bool ld_ok = INTERIOR || (cb >= 0 && cb < A.w);
+    uint32_t bmask = INTERIOR ? 0xffffffffu : 0u;
+    int cm[4] = {-1, -1, -1, -1};
+    if constexpr (!INTERIOR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = (cb + j) >= 0 && (cb + j) < A.w;
+            cm[j] = in ? -1 : 0;
+            bmask |= in ? (0xffu << (8 * j)) : 0u;
+        }
+    }
+    uint32_t col_off = ld_ok ? (uint32_t)cb : 0u;
+    // the exchanged layout of an output row (see "the flow stores"): lane l stores chunks l and l + 64 of the row
+    const int x0 = tile * G::OUT_W;
+    const int nv = min(x0 + G::OUT_W, A.w) - x0;
+    uint32_t l16 = 16u * (uint32_t)lane;
+    const int lim = 8 * nv - 16, c16 = 16 * lane;
+    const bool st_lo4 = c16 <= lim, st_lo2 = c16 == lim + 8, st_hi4 = c16 <= lim - 1024, st_hi2 = c16 == lim + 8 - 1024;
+    // lane offsets of the two stores; a lane that has nothing to store points outside the resource (the store is dropped)
+    uint32_t vo_lo = st_lo4 ? l16 : (uint32_t)kOob, vo_hi = st_hi4 ? l16 + 1024u : (uint32_t)kOob;
+    const bool ragged = __any(st_lo2 || st_hi2) != 0; // a level of odd width ends inside a chunk: that lane stores one pixel
+    const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
+    const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
+
+    const int y_lim = min(min(ye + R + 1, A.h), A.row_end);
+    const int y_min = max(0, A.row0);
+    const int y_first = ys - R; // first derivative row this strip needs
+    // byte offset of image row y in the planes, kOob where the row is the zero border or not needed: one unsigned range test
+    const int span_in = max(y_lim - y_min, 0);
+    const int y_min_out = max(y_min, y_first - 1), span_out = max(y_lim - y_min_out, 0); // (rows of the leaving window before y_first - 1 are never used)
+    auto row_off = [&](int y) -> int { return (uint32_t)(y - y_min) < (uint32_t)span_in ? (y - A.row0) * A.pitch : kOob; };
+    auto row_off_out = [&](int y) -> int { return (uint32_t)(y - y_min_out) < (uint32_t)span_out ? (y - A.row0) * A.pitch : kOob; };
+
+    // ---- fused shift (see lk_wave_impl): per lane the base column of the shifted dword and the byte selectors
+    const float su = A.uv ? A.uv[0] : 0.0f, sv = A.uv ? A.uv[1] : 0.0f;
+    uint32_t nb_off = 0u, sel = 0u, own_sel = 0u;
+    bool all_in;
+    {
+        int n[4], nb = 0x7fffffff;
+        bool in[4], lane_all_in = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = cb + j;
+            const float tx = (float)x + su;
+            in[j] = x >= 0 && x < A.w && tx > -1.0f && tx < (float)A.w;
+            n[j] = in[j] ? (int)tx : 0;
+            if (in[j]) nb = min(nb, n[j]);
+        }
+        nb = max(0, min(nb == 0x7fffffff ? 0 : nb, A.pitch - 4)); // the dword stays inside the row pitch
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = cb + j;
+            const uint32_t sj = !(x >= 0 && x < A.w) ? 0x0cu : (in[j] ? (uint32_t)(n[j] - nb) : (uint32_t)(4 + j));
+            sel |= sj << (8 * j);
+            own_sel |= (!(x >= 0 && x < A.w) ? 0x0cu : (uint32_t)(4 + j)) << (8 * j);
+            if (x >= 0 && x < A.w && !in[j]) lane_all_in = false;
+        }
+        nb_off = (uint32_t)nb;
+        all_in = __all(lane_all_in) != 0;
+    }
+    const int y_none = (A.h + 2) / 3, y_part = (A.h % 3) ? A.h / 3 : -1;
+    // The row map y -> (int)((float)y + v) as a table of BYTE OFFSETS for 64 consecutive rows (lane i: row map_base + i): the
+    // offset of the target row in the planes, or kOob when row y is not needed (outside [y_min, y_lim)) or its target is outside
+    // the image or the buffer.  A step reads its two entries with v_readlane_b32.
+    int map_base = 0, row_tab = kOob;
+    auto refresh_map = [&](int y0) {
+        map_base = y0;
+        const int y = y0 + lane;
+        const float ty = (float)y + sv;
+        const bool yin = ty > -1.0f && ty < (float)A.h;
+        const int ny = yin ? (int)ty : 0;
+        const bool ok = y >= y_min && y < y_lim && yin && ny >= A.row0 && ny < A.row_end;
+        row_tab = ok ? (ny - A.row0) * A.pitch : kOob;
+    };
+    struct NextRaw {
+        uint32_t own, sh; // the row's own dword / the dword at the shifted position (0 where not needed)
+        int miss;         // wave-uniform: all ones when the shifted row does not exist
+    };
+    // po: row_off / row_off_out of the same row y (the planes share their geometry: the own row of next sits where prev's does)
+    auto fetch_next = [&](int y, int po) -> NextRaw {
+        NextRaw r;
+        const int e = __builtin_amdgcn_readlane(row_tab, y - map_base);
+        r.sh = __builtin_amdgcn_raw_buffer_load_b32(rs_next, nb_off, e, 0);
+        r.miss = e >> 31;
+        asm("" : "=v"(r.own)); // (never selected while every byte comes from the shifted dword: left undefined, not zeroed)
+        // an interior tile whose target row exists takes every byte from the shifted dword; otherwise (a column or the row
+        // leaves the image) the pixels concerned keep their own byte while 3 * (y * w + x) < w * h, else 0 (OptFlowCPU.cpp:247)
+        if (__builtin_expect(!all_in || r.miss != 0, 0)) {
+            r.own = __builtin_amdgcn_raw_buffer_load_b32(rs_next, col_off, y < y_none ? po : kOob, 0);
+            if (y == y_part) {
+                uint32_t km = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (3ll * (cb + j) < (long long)A.w * (A.h % 3)) km |= 0xffu << (8 * j);
+                r.own &= km;
+            }
+        }
+        return r;
+    };
+    // both selectors give 0 for columns outside the image, and own == sh == 0 for rows outside it
+    auto finish_next = [&](const NextRaw &r) -> uint32_t {
+        // selector = miss ? own_sel : sel, as ONE v_bfi_b32 on the scalar mask (written as bit operations hipcc turns it into a
+        // compare, a 64-bit select and a v_cndmask)
+        uint32_t sx;
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(sx) : "s"(r.miss), "v"(own_sel), "v"(sel));
+        return __builtin_amdgcn_perm(r.own, r.sh, sx);
+    };
+    auto fetch_prev = [&](int po) -> uint32_t { return __builtin_amdgcn_raw_buffer_load_b32(rs_prev, col_off, po, 0); };
+    auto finish_row = [&](uint32_t raw) -> uint32_t {
+        if constexpr (INTERIOR) return raw;
+        else return raw & bmask;
+    };
+    auto load_pair = [&](int y, bool out, uint32_t &p, uint32_t &n) {
+        const int po = out ? row_off_out(y) : row_off(y);
+        p = finish_row(fetch_prev(po));
+        n = finish_next(fetch_next(y, po));
+    };
+
+    // (the folded priming and the slot rotation are those of lk_wave_impl)
+    constexpr int H = OFX_LK_FOLD_PRIMING ? R - 1 : 0;
+    constexpr int PR = 2 * R - H;
+    const int y_lo0 = y_first + H;
+    const int nsteps = (ye - ys) + PR;
+    RowPk<MODE> wp[3];
+    const s2 two = pk_two();
+    refresh_map(y_first - 1);
+    {
+        uint32_t pi, ni, po = 0u, no = 0u;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            load_pair(y_lo0 - 1 + t, false, pi, ni);
+            if constexpr (H > 0) load_pair(y_first - 1 + t, true, po, no);
+            unpack_pk(pi, ni, po, no, wp[t]);
+        }
+    }
+    int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
+    // byte offset, in the flow, of the tile's first output pixel in the row the next emitting step writes
+    // (made scalar by hand, and recomputed per step rather than carried: as a running sum hipcc keeps it in a VGPR and wraps
+    // every store in a waterfall loop)
+    int fso0 = __builtin_amdgcn_readfirstlane(((ys - A.flow_row0) * A.w + x0) * 8);
+    int fstep = A.w * 8;
+    pin_scalar(fso0);
+    pin_scalar(fstep);
+
+    auto body = [&](auto K, int s) {
+        constexpr int k = decltype(K)::value; // s mod 3
+        const int yy = y_lo0 + s;             // derivative row entering the window (low halves)
+        const int yo = yy - NS;               // derivative row leaving it (high halves, once the folded priming is over)
+        const bool folded = H > 0 && s < H;   // high halves: the entering row y_first + s
+        const int yh = folded ? y_first + s : yo;
+
+        // the loads of the rows the next step adds, finished at the end of this step, before its stores (one vmcnt for both kinds)
+        if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
+        const int ro = (H > 1 && s + 1 < H) ? y_first + s + 2 : yo + 2; // b row of the high stream's next step
+        const int po_in = row_off(yy + 2), po_out = row_off_out(ro);
+        const uint32_t pf_ip = fetch_prev(po_in), pf_op = fetch_prev(po_out);
+        const NextRaw pf_in = fetch_next(yy + 2, po_in);
+        // (a row of the leaving window before y_first - 1 is never used and may lie below the table: its pixels are zeros)
+        NextRaw pf_on;
+        if (ro >= y_first - 1) {
+            pf_on = fetch_next(ro, po_out);
+        } else {
+            pf_on.own = pf_on.sh = 0u;
+            pf_on.miss = -1;
+        }
+        const bool emit = s >= PR;
+
+        const uint32_t him = folded ? 0x00010000u : (yo >= y_first ? 0xffff0000u : 0u);
+        uint32_t rowm = ((uint32_t)yy < (uint32_t)A.h ? 0x00000001u : 0u) | ((uint32_t)yh < (uint32_t)A.h ? him : 0u);
+        // (one scalar multiplier pair for all columns.  readfirstlane, not pin_scalar: hipcc's uniformity analysis does not see
+        // that this value -- or the store offset below -- is wave-uniform, and an "s" constraint on it fails to compile)
+        if constexpr (INTERIOR) rowm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowm);
+        const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
+        s2 ix[4], iy[4], it[4];
+        derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
+        accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
+        auto take_rows = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+            pin_row(wp[k]);
+        };
+
+        f32x4 xlo, xhi;
+        asm("" : "=v"(xlo), "=v"(xhi));
+        if (emit) {
+            float uv[8];
+#if OFX_LK_HBOX_LOCKSTEP
+            // the five box sums stage by stage (hbox4x5): no wait states between the dependent DPP operations of one quantity
+            int hb[5][4];
+            {
+                int va[5][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) va[0][j] = vxx[j], va[1][j] = vyy[j], va[2][j] = vxy[j], va[3][j] = vxt[j], va[4][j] = vyt[j];
+                hbox4x5<R>(va, hb);
+            }
+            const int(&hxx)[4] = hb[0], (&hyy)[4] = hb[1], (&hxy)[4] = hb[2], (&hxt)[4] = hb[3], (&hyt)[4] = hb[4];
+#else
+            int hxx[4], hyy[4], hxy[4], hxt[4], hyt[4];
+            hbox4<R>(vxx, hxx);
+            hbox4<R>(vyy, hyy);
+            hbox4<R>(vxy, hxy);
+            hbox4<R>(vxt, hxt);
+            hbox4<R>(vyt, hyt);
+#endif
+#ifdef OFX_X_NOSOLVE // timing experiment (results wrong by construction)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uv[2 * j] = __int_as_float(hxx[j] ^ hxy[j] ^ hxt[j]);
+                uv[2 * j + 1] = __int_as_float(hyy[j] ^ hyt[j]);
+            }
+#else
+            solve_lane<MODE, FAST>(hxx, hyy, hxy, hxt, hyt, sopt, uv);
+#endif
+            *(__attribute__((address_space(3))) f32x4 *)(xl_w) = f32x4{uv[0], uv[1], uv[2], uv[3]};
+            *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const lds_ptr xl_r = xl_base + lane_off_var(l16);
+            xlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
+            xhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
+        }
+        take_rows();
+        if (emit) {
+#if defined(OFX_X_TINYSTORE) // timing experiment: every row lands in the first MB of the flow (L2 hits, no HBM write stream)
+            const int fso = __builtin_amdgcn_readfirstlane((fso0 + (s - PR) * fstep) & 0xff000);
+#else
+            const int fso = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep); // this row's offset in the flow
+#endif
+            // two gap-free streaming stores of 1 KB; the lanes past the tile's end are dropped by the resource's range check
+#if defined(OFX_X_NOSTORE) // timing experiment: the row is exchanged but never stored
+            asm volatile("" : : "v"(xlo), "v"(xhi), "s"(fso));
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xlo), rs_flow, vo_lo, fso, OFX_LK_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xhi), rs_flow, vo_hi, fso, OFX_LK_STORE_AUX);
+#endif
+            if (__builtin_expect(ragged, 0)) { // the one lane whose chunk holds a single pixel
+                const u32x4 ql = __builtin_bit_cast(u32x4, xlo), qh = __builtin_bit_cast(u32x4, xhi);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{ql.x, ql.y}, rs_flow, st_lo2 ? l16 : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{qh.x, qh.y}, rs_flow, st_hi2 ? l16 + 1024u : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
+            }
+        }
+    };
+
+#if OFX_LK_PROGRESS_PRIORITY
+    const int q1 = nsteps / 4, q2 = nsteps / 2, q3 = nsteps - nsteps / 4;
+    __builtin_amdgcn_s_setprio(3);
+#define OFX_LK_PRIO_STEP()                               \
+    do {                                                 \
+        if (s >= q3) __builtin_amdgcn_s_setprio(0);      \
+        else if (s >= q2) __builtin_amdgcn_s_setprio(1); \
+        else if (s >= q1) __builtin_amdgcn_s_setprio(2); \
+    } while (0)
+#else
+#define OFX_LK_PRIO_STEP() ((void)0)
+#endif
+    int s = 0;
+    while (true) {
+        body(std::integral_constant<int, 0>{}, s);
+        if (++s >= nsteps) break;
+        body(std::integral_constant<int, 1>{}, s);
+        if (++s >= nsteps) break;
+        body(std::integral_constant<int, 2>{}, s);
+        if (++s >= nsteps) break;
+        OFX_LK_PRIO_STEP();
+    }
+#undef OFX_LK_PRIO_STEP
+}
+
+} // namespace ofx_dev

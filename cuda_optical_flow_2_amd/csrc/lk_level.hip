@@ -196,6 +196,13 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;
     if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
+    // the stream kernel's LK stage addresses planes and flow through buffer resources with 32-bit offsets (lk_body_buf.h)
+    for (int i = 0; i < m; ++i) {
+        const LkArgs &a = lv[i].a;
+        OFX_REQUIRE((long long)(a.row_end - a.row0) * a.pitch < (1ll << 31) && (long long)(a.out_y1 - a.flow_row0) * a.w * 8 < (1ll << 31),
+                    "ofx_stream_launch: level %dx%d is too large for one launch item (planes and flow rows must stay below 2 GB: "
+                    "shard the level by rows)", a.w, a.h);
+    }
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::stream_lk_float_fast(window >> 1, lv, m, S, stage_blocks, lds, st);

@@ -455,6 +455,9 @@ extern "C" int ofx_session_run_level(ofx_session *s, int level, void *stream)
         ofx_set_error("ofx_session_run_level: need a previous and a next frame (load, build, swap, load, build)");
         return OFX_E_STATE;
     }
+    // (the flow buffers of such a session start above the own rows -- fl0 < own0 -- and only the stream pipeline addresses them so)
+    OFX_REQUIRE(!(s->p.sharded && s->p.iters > 1), "ofx_session_run_level: refinement iterations on a sharded session run through the stream "
+                                                    "pipeline (ofx_session_stream_*)");
     const uint8_t *next = s->plane[1][level];
     if (level != s->p.levels - 1) {
         // shift every row the LK stencil will read: own rows +- (radius + 1), clipped to the buffer
@@ -1141,14 +1144,14 @@ extern "C" int ofx_calc_opt_flow_host(const uint8_t *h_prev3, const uint8_t *h_n
     const size_t plane = (size_t)pitch * (size_t)h + 64;
     // buffers come from the calling thread's cached arena (compat_scratch.h): no allocation per call in a frame loop
     ofx_compat::Scratch sc;
-    uint8_t *d_p3 = sc.upload(h_prev3, 3 * n), *d_n3 = sc.upload(h_next3, 3 * n);
     uint8_t *d_p1 = sc.alloc<uint8_t>(plane), *d_n1 = sc.alloc<uint8_t>(plane), *d_s1 = sc.alloc<uint8_t>(plane);
     float *d_flow = sc.alloc<float>(2 * n);
     float *d_coarse = sc.alloc<float>(2 * OFX_MAX_LEVELS + 2); // 2 floats per level, then the shift vector
     if (!sc.ok()) return sc.rc();
     float *d_uv = d_coarse + 2 * OFX_MAX_LEVELS;
-    OFX_TRY(ofx_extract_ch0(d_p3, d_p1, w, h, pitch, nullptr));
-    OFX_TRY(ofx_extract_ch0(d_n3, d_n1, w, h, pitch, nullptr));
+    // the reference reads channel 0 only (OptFlowGpu.cu:1079): it is picked out while the images are staged, a third of the bytes
+    OFX_TRY(ofx_compat::stage_h2d_ch0(d_p1, pitch, h_prev3, w, h));
+    OFX_TRY(ofx_compat::stage_h2d_ch0(d_n1, pitch, h_next3, w, h));
     ofx_geom g{w, h, pitch, 0, h, 0, h};
     const uint8_t *d_next = d_n1;
     if (level != max_level - 1) {
@@ -1178,6 +1181,10 @@ extern "C" int ofx_compose_flow_host(float *const *h_flow_pyr, int w, int h, int
 {
     OFX_REQUIRE(h_flow_pyr && h_dst && w > 0 && h > 0, "ofx_compose_flow_host: bad arguments");
     OFX_REQUIRE(levels >= 1 && levels <= OFX_MAX_LEVELS && level >= 0 && level < levels, "ofx_compose_flow_host: bad level");
+    // level k is uploaded as (w >> s) x (h >> s), s = k - level, and the kernel reads its row i >> s for i < h: with h not a
+    // multiple of 2^s that is one row past the upload (the reference has the same overrun, on host memory, main.cu:138-147)
+    OFX_REQUIRE(w % (1 << (levels - 1 - level)) == 0 && h % (1 << (levels - 1 - level)) == 0,
+                "ofx_compose_flow_host: %dx%d is not a multiple of %d (the coarsest level's scale)", w, h, 1 << (levels - 1 - level));
     ofx_compat::Scratch sc;
     const float *d_lv[OFX_MAX_LEVELS] = {};
     for (int k = level; k < levels; ++k) {

@@ -95,6 +95,7 @@ _SIGS = {
     "ofx_session_stream_begin": [_vp],
     "ofx_session_corner_status": [_vp, C.POINTER(_i), _vp],
     "ofx_session_pair_status": [_vp, _i, C.POINTER(_i), _vp],
+    "ofx_stage_threads": [],
     "ofx_debug_stream_trace": [_vp, _i, C.POINTER(_i)],
     "ofx_session_flow_of": [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)],
     "ofx_session_stream_submit": [_vp, _vp, _i, _vp, C.POINTER(_i)],

@@ -492,6 +492,12 @@ int ofx_session_timing_read_kind(ofx_session *s, int kind, double *avg_us, doubl
 int ofx_calc_opt_flow_host(const uint8_t *h_prev3, const uint8_t *h_next3, int w, int h, float **h_flow_pyr,
                            int level, int max_level, int window, int mode);
 
+/* The host-pointer entry points (this one, ofx_compose_flow_host and the gpu:: / cpu:: wrappers) move transfers of 3 MB and
+ * more in 2 MB chunks through pinned bounce buffers, on several threads at once: the caller and a small pool the library keeps
+ * (environment OFX_STAGE_THREADS = pool size, default 3; -1 = plain hipMemcpy).  Returns the number of threads that share a
+ * transfer.  The calls stay synchronous and retain nothing of the caller's. */
+int ofx_stage_threads(void);
+
 /* main.cu:138-147 (the dense field visualizeFlowField samples) with host pointers: h_flow_pyr[k] for k >= level are the
  * host flow levels gpu::calc_opt_flow filled, (w, h) is the size of `level`; h_dst receives 2*w*h floats. */
 int ofx_compose_flow_host(float *const *h_flow_pyr, int w, int h, int levels, int level, float *h_dst);
