@@ -171,7 +171,10 @@ void bilinear_filter_3ch(unsigned char *src, unsigned char *gray, unsigned char 
     const size_t n = (size_t)w * h * 3;
     Scratch s;
     unsigned char *d_in = s.upload(src, n), *d_g = (gray == src) ? d_in : s.upload(gray, n), *d_out = s.alloc<unsigned char>(n);
-    if (s.ok()) s.run(ofx_bilateral_3ch(d_in, d_g, d_out, w, h, ww, wh, sigmaS, sigmaB, nullptr));
+    // (the reference's signature has no mode: ofx_bilateral_wrappers_fast / OFX_BILATERAL_FAST select the +-1 LSB kernel)
+    const bool fast = ofx_bilateral_wrappers_fast(-1) != 0 && (ww & 1) && (wh & 1) && ww <= 13 && wh <= ww;
+    if (s.ok()) s.run(fast ? ofx_bilateral_3ch_fast(d_in, d_g, d_out, w, h, ww, wh, sigmaS, sigmaB, nullptr)
+                           : ofx_bilateral_3ch(d_in, d_g, d_out, w, h, ww, wh, sigmaS, sigmaB, nullptr));
     s.download(dest, d_out, n);
     status() = s.rc();
 }

@@ -41,7 +41,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00027000);
 }
 
-template <int R, int MODE, bool FAST, bool INTERIOR>
+// DMA (OFX_LK_DMA_ROWS): the rows of a step are fetched TWO steps ahead, straight into LDS (buffer_load ... lds: no VGPR holds
+// them while they are in flight), six per step -- prev / shifted next / own next, for the entering and the leaving window -- into
+// one of two sets of six 256-byte rows behind the wave's exchange row.  The point is the wait: gfx9 counts loads and stores in
+// ONE counter, so the march's "wait for the rows fetched a step ahead" was also a wait for the two flow stores of the step
+// before -- 28 us of a 242 us launch (profiles/r03_ablation.txt: the launch without its stores).  Loads return in order among
+// themselves, so with the next step's six loads already issued behind them, s_waitcnt vmcnt(6) means "this step's rows have
+// arrived" whatever the stores are doing: if one of this step's rows were still out, all six younger loads would be too, and
+// the count could not be six.  Stores may now take up to two steps to complete before a wave waits for them.
+#ifndef OFX_LK_DMA_ROWS
+#define OFX_LK_DMA_ROWS 1
+#endif
+constexpr int kLkDmaRowBytes = 256, kLkDmaRows = 6, kLkDmaSetBytes = kLkDmaRows * kLkDmaRowBytes;
+constexpr int kLkWaveLdsDma = kLkWaveLds + 2 * kLkDmaSetBytes; // the exchange row, then two sets of fetched rows
+
+template <int R, int MODE, bool FAST, bool INTERIOR, bool DMA>
 __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
@@ -194,6 +208,51 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         n = finish_next(fetch_next(y, po));
     };
 
+    // ---- DMA form: issue the six rows of a step into LDS set `set`; take them out again a step later
+    const uint32_t dma_base = (uint32_t)(uintptr_t)((lds_ptr)xlds + kLkWaveLds); // LDS byte address of set 0, row 0 (wave-uniform)
+    uint32_t dma_lane = dma_base + 4u * (uint32_t)lane;                           // this lane's dword in set 0, row 0
+    auto dma_load = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, int soff, uint32_t lds_addr) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(uintptr_t)lds_addr, 4, voff, soff, 0, 0);
+    };
+    // own row of `next` for image row y (po: its offset): needed when a column target or the row target leaves the image
+    // Four rows per step when every column target of the wave lies inside the image (all_in: the shifted dwords supply every
+    // byte while the shifted ROW exists), six otherwise (the own rows of next as well).  all_in waves meet a row whose target
+    // leaves the image only at the image's top or bottom: they fetch its own row when they take it (take_one; an ordinary load,
+    // a stall of one memory round trip on those few rows).
+    auto issue_rows = [&](int set, int y_in, int y_out) {
+        const int po_in = row_off(y_in), po_out = row_off_out(y_out);
+        const int e_in = __builtin_amdgcn_readlane(row_tab, y_in - map_base);
+        // (a row of the leaving window before y_first - 1 is never used and may lie below the table)
+        const int e_out = y_out >= y_first - 1 ? __builtin_amdgcn_readlane(row_tab, y_out - map_base) : kOob;
+        const uint32_t a = dma_base + (uint32_t)(set * kLkDmaSetBytes);
+        dma_load(rs_prev, col_off, po_in, a);
+        dma_load(rs_prev, col_off, po_out, a + 1 * kLkDmaRowBytes);
+        dma_load(rs_next, nb_off, e_in, a + 2 * kLkDmaRowBytes);
+        dma_load(rs_next, nb_off, e_out, a + 3 * kLkDmaRowBytes);
+        if (__builtin_expect(!all_in, 0)) {
+            dma_load(rs_next, col_off, y_in < y_none ? po_in : kOob, a + 4 * kLkDmaRowBytes);
+            dma_load(rs_next, col_off, y_out < y_none ? po_out : kOob, a + 5 * kLkDmaRowBytes);
+        }
+    };
+    // the row of next for image row y from what arrived (sh: shifted dword; own: own dword, fetched only for !all_in waves)
+    auto take_one = [&](int y, bool out, uint32_t sh, uint32_t own) -> uint32_t {
+        const int e = (!out || y >= y_first - 1) ? __builtin_amdgcn_readlane(row_tab, y - map_base) : kOob;
+        NextRaw r;
+        r.sh = sh;
+        r.miss = e >> 31;
+        r.own = own;
+        if (__builtin_expect(r.miss != 0 && all_in, 0)) // the row's target left the image (or the row is not needed: then own is 0 too)
+            r.own = __builtin_amdgcn_raw_buffer_load_b32(rs_next, col_off, y < y_none ? (out ? row_off_out(y) : row_off(y)) : kOob, 0);
+        if (__builtin_expect(y == y_part && (!all_in || r.miss != 0), 0)) {
+            uint32_t km = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (3ll * (cb + j) < (long long)A.w * (A.h % 3)) km |= 0xffu << (8 * j);
+            r.own &= km;
+        }
+        return finish_next(r);
+    };
+
     // (the folded priming and the slot rotation are those of lk_wave_impl)
     constexpr int H = OFX_LK_FOLD_PRIMING ? R - 1 : 0;
     constexpr int PR = 2 * R - H;
@@ -211,6 +270,10 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             unpack_pk(pi, ni, po, no, wp[t]);
         }
     }
+    if constexpr (DMA) { // the rows step 0 takes at its end (the b rows of step 1): y_lo0 + 2 and the high stream's
+        const int ro0 = (H > 1 && 1 < H) ? y_first + 2 : y_lo0 - NS + 2;
+        issue_rows(0, y_lo0 + 2, ro0);
+    }
     int vxx[4] = {0, 0, 0, 0}, vyy[4] = {0, 0, 0, 0}, vxy[4] = {0, 0, 0, 0}, vxt[4] = {0, 0, 0, 0}, vyt[4] = {0, 0, 0, 0};
     // byte offset, in the flow, of the tile's first output pixel in the row the next emitting step writes
     // (made scalar by hand, and recomputed per step rather than carried: as a running sum hipcc keeps it in a VGPR and wraps
@@ -227,19 +290,24 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         const bool folded = H > 0 && s < H;   // high halves: the entering row y_first + s
         const int yh = folded ? y_first + s : yo;
 
-        // the loads of the rows the next step adds, finished at the end of this step, before its stores (one vmcnt for both kinds)
-        if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
         const int ro = (H > 1 && s + 1 < H) ? y_first + s + 2 : yo + 2; // b row of the high stream's next step
-        const int po_in = row_off(yy + 2), po_out = row_off_out(ro);
-        const uint32_t pf_ip = fetch_prev(po_in), pf_op = fetch_prev(po_out);
-        const NextRaw pf_in = fetch_next(yy + 2, po_in);
-        // (a row of the leaving window before y_first - 1 is never used and may lie below the table: its pixels are zeros)
-        NextRaw pf_on;
-        if (ro >= y_first - 1) {
-            pf_on = fetch_next(ro, po_out);
+        uint32_t pf_ip = 0u, pf_op = 0u;
+        NextRaw pf_in = {0u, 0u, -1}, pf_on = {0u, 0u, -1};
+        if constexpr (DMA) {
+            // issue the rows of the step AFTER the next one (this step's were issued a step ago and are taken below); the table
+            // must still hold this step's rows then: yo + 2 is the lowest of them
+            const int ro_next = (H > 1 && s + 2 < H) ? y_first + s + 3 : yo + 3;
+            if (yy + 3 - map_base >= 64) refresh_map(min(yo + 2, ro));
+            issue_rows((s + 1) & 1, yy + 3, ro_next);
         } else {
-            pf_on.own = pf_on.sh = 0u;
-            pf_on.miss = -1;
+            // the loads of the rows the next step adds, finished at the end of this step, before its stores (one vmcnt for both kinds)
+            if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
+            const int po_in = row_off(yy + 2), po_out = row_off_out(ro);
+            pf_ip = fetch_prev(po_in);
+            pf_op = fetch_prev(po_out);
+            pf_in = fetch_next(yy + 2, po_in);
+            // (a row of the leaving window before y_first - 1 is never used and may lie below the table: its pixels are zeros)
+            if (ro >= y_first - 1) pf_on = fetch_next(ro, po_out);
         }
         const bool emit = s >= PR;
 
@@ -254,7 +322,20 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
         auto take_rows = [&]() {
             __builtin_amdgcn_sched_barrier(0);
-            unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+            if constexpr (DMA) {
+                // this step's rows have arrived once at most the younger loads (the next step's four or six) are outstanding
+                if (__builtin_expect(all_in, 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                const lds_ptr rp = (lds_ptr)(uintptr_t)(dma_lane + (uint32_t)((s & 1) * kLkDmaSetBytes));
+                auto row = [&](int i) { return *(const __attribute__((address_space(3))) uint32_t *)(rp + i * kLkDmaRowBytes); };
+                const uint32_t a_p = row(0), a_po = row(1), a_n = row(2), a_no = row(3);
+                uint32_t o_n, o_no;
+                asm("" : "=v"(o_n), "=v"(o_no)); // (never selected while every byte comes from the shifted dwords)
+                if (__builtin_expect(!all_in, 0)) o_n = row(4), o_no = row(5);
+                unpack_pk(finish_row(a_p), take_one(yy + 2, false, a_n, o_n), finish_row(a_po), take_one(ro, true, a_no, o_no), wp[k]);
+            } else {
+                unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+            }
             pin_row(wp[k]);
         };
 
@@ -342,6 +423,8 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         OFX_LK_PRIO_STEP();
     }
 #undef OFX_LK_PRIO_STEP
+    // the rows issued by the last step are never taken: they must have landed before the wave gives its LDS back
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 } // namespace ofx_dev

@@ -81,7 +81,8 @@ using ofx_launch::g_trace_header;
 #ifndef OFX_STREAM_MIN_BLOCKS
 #define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 4)
 #endif
-template <int R, int MODE, bool FAST>
+// DMA: the LK stage fetches its rows two steps ahead through LDS (lk_body_buf.h); chosen per launch by launch_stream_r
+template <int R, int MODE, bool FAST, bool DMA>
 __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
                                      reinterpret_cast<int *>(lds + kCornerScratch - 32));
         }
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false, FAST>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLds);
+        lk_wave<R, MODE, false, false, FAST, DMA>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -243,13 +244,18 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
     return OFX_OK;
 }
 
-template <int R, int MODE, bool FAST>
-int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
+// Deep fetch (DMA = true) pays where a step's row loads come from HBM -- measured on MI355X (profiles/r03_ablation.txt): 8K,
+// two frames per launch: 279 vs 295 us (-5 %); 4K with its frames in the Infinity Cache: 247 vs 237 us (+4 %: the form costs
+// ~60 more scalar instructions per step, and the loads are short there) -- so it is chosen by the size of the largest level:
+// planes of 16 Mpx and more do not stay cached between their two uses.  OFX_LK_DMA=0 / 1 overrides.
+template <int R, int MODE, bool FAST, bool DMA>
+int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
+    constexpr size_t wave_lds = DMA ? kLkWaveLdsDma : kLkWaveLds;
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
     // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
-    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST>, 256, 16 * 1024, 1, 2);
-    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST>, 256, 16 * 1024, 1, 4);
+    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA>, 256, 4 * wave_lds, 1, 2);
+    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA>, 256, 4 * wave_lds, 1, 4);
     int pairs = 0;
     for (int i = 0; i < n; ++i) pairs += (lv[i].a.w == lv[0].a.w && lv[i].a.h == lv[0].a.h) ? 1 : 0;
     const int capacity = pairs >= 2 ? capacity2 : capacity1;
@@ -268,10 +274,22 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
         corner_lds = need > corner_lds ? need : corner_lds;
     }
     if (lds < corner_lds) lds = corner_lds;
-    if (lds < 4 * (size_t)kLkWaveLds) lds = 4 * (size_t)kLkWaveLds; // an LK block: four waves, each with its exchange row
-    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST>), dim3((unsigned)blocks), dim3(256), lds, st, S);
+    if (lds < 4 * wave_lds) lds = 4 * wave_lds; // an LK block: four waves, each with its exchange row (and its fetched rows)
+    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST, DMA>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
+}
+
+template <int R, int MODE, bool FAST>
+int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
+{
+#if OFX_LK_BUFFER_PATH && OFX_LK_DMA_ROWS
+    static const int forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
+    long max_px = 0;
+    for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
+    if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true>(lv, n, S, stage_blocks, lds, st);
+#endif
+    return launch_stream_rd<R, MODE, FAST, false>(lv, n, S, stage_blocks, lds, st);
 }
 
 template <int MODE, bool FAST>

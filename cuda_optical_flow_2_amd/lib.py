@@ -74,6 +74,8 @@ _SIGS = {
     "ofx_solve_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "ofx_generate_gaussian_kernel": [_d, _i, _vp],
     "ofx_bilateral_3ch": [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _vp],
+    "ofx_bilateral_3ch_fast": [_vp, _vp, _vp, _i, _i, _i, _i, _d, _d, _vp],
+    "ofx_bilateral_wrappers_fast": [_i],
     "ofx_sub_u8": [_vp, _vp, C.c_size_t, _vp, _vp],
     "ofx_srm_3ch_u8": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "ofx_downscale_mask_3ch": [_vp, _vp, _i, _i, _vp, _i, _i, _vp],

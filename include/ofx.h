@@ -310,6 +310,16 @@ void ofx_generate_gaussian_kernel(double sigma_s, int kernel_size, double *h_dst
 int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int ww, int wh,
                       double sigma_s, double sigma_b, void *stream);
 
+/* The same filter within SURVEY 8c's tolerance for this stage (+-1 LSB of the reference's byte), several times faster: float
+ * accumulators, the range weight evaluated (v_exp_f32) instead of looked up, the quotient formed around the centre value for
+ * grey images.  Odd ww <= 13, odd wh <= ww.  Opt-in: ofx_bilateral_3ch stays the bit-exact kernel. */
+int ofx_bilateral_3ch_fast(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, int ww, int wh,
+                           double sigma_s, double sigma_b, void *stream);
+/* gpu::bilinear_filter / cpu::bilinear_filter_3ch have the reference's signatures and carry no mode: this process-wide switch
+ * makes them run ofx_bilateral_3ch_fast (on != 0) or the bit-exact kernel (on == 0, the default; environment
+ * OFX_BILATERAL_FAST=1 starts with it on).  on < 0 only queries.  Returns the previous setting. */
+int ofx_bilateral_wrappers_fast(int on);
+
 /* the remaining functions of namespace cpu (OptFlowCpu.hpp:3-184), device-resident, so that the cpu:: call surface of
  * include/OptFlowCpu.hpp runs on the MI355X as well */
 /* cpu::sub_arr, OptFlowCPU.cpp:11-17 (bytes, wrapping) */

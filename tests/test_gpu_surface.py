@@ -194,6 +194,37 @@ def test_replay_of_main_cu_frame_loop(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (130, 131)])
+def test_fast_bilateral_filter_is_within_one_lsb(gpu, cpu, oracle, golden, size):
+    """ofx_bilateral_3ch_fast (float accumulators, v_exp_f32 range weights, quotient around the centre value) against the
+    oracle's bit-exact filter: every byte within +-1 (SURVEY 8c's tolerance for this stage), on the sizes and windows of the
+    exact kernel's test, colour and grey, through the gpu:: / cpu:: wrappers with the process-wide switch on -- and the switch
+    off again gives the exact bytes."""
+    from cuda_optical_flow_2_amd import lib
+
+    L = lib.load()
+    w, h = size
+    rng = np.random.default_rng(w * 1000 + h + 7)
+    colour = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    grey = oracle.grayscale_avg(colour)
+    smooth = synth.to_3ch(synth.smooth_pair(w, h, 0, 0, seed=5)[1])   # (natural-ish content: the quotient sits near the centre value)
+    assert L.ofx_bilateral_wrappers_fast(1) == 0
+    try:
+        worst, differ = 0, 0
+        for (ww, wh, ss, sb) in ((9, 9, 2.0, 10.0), (5, 5, 1.5, 20.0), (7, 3, 1.0, 5.0), (13, 13, 3.0, 40.0)):
+            for src, gr, what in ((grey, grey, "grey"), (colour, grey, "colour"), (smooth, smooth, "smooth grey")):
+                got = gpu.bilinear_filter(src, gr, ww, wh, ss, sb).astype(np.int32)
+                want = oracle.bilateral_3ch(src, gr, ww, wh, ss, sb).astype(np.int32)
+                d = np.abs(got - want)
+                assert d.max() <= 1, f"{what} {ww}x{wh} at {w}x{h}: off by {d.max()}"
+                worst, differ = max(worst, int(d.max())), differ + int((d != 0).sum())
+        got = cpu.bilinear_filter_3ch(colour, grey, 9, 9, 2.0, 10.0).astype(np.int32)
+        assert np.abs(got - oracle.bilateral_3ch(colour, grey, 9, 9, 2.0, 10.0).astype(np.int32)).max() <= 1
+    finally:
+        assert L.ofx_bilateral_wrappers_fast(0) == 1
+    assert_same(gpu.bilinear_filter(grey, grey, 9, 9, 2.0, 10.0), oracle.bilateral_3ch(grey, grey, 9, 9, 2.0, 10.0), "exact again")
+
+
+@pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (130, 131)])
 def test_bilateral_filter_tiled_kernel_matches_oracle(gpu, cpu, oracle, size):
     """The tiled bilateral kernel (LDS neighbourhood, range table by signed difference, out-of-image taps as +0.0) is the
     reference's arithmetic in the reference's order: bit-exact against the oracle on sizes that are not multiples of the
