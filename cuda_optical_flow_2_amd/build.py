@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if force or jobs or _stale(OUT, objs):
-        cmd = [cc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs
+        cmd = [cc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)

@@ -1,6 +1,8 @@
 // Error channel, argument checks and small queries of libofx_hip.so.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "ofx_internal.h"
 
@@ -51,4 +53,41 @@ int ofx_check_halo(const ofx_geom *g, int halo, const char *who)
                 "%s: rows [%d,%d) are needed (halo %d) but the buffer holds [%d,%d)", who, lo, hi, halo, g->row0,
                 g->row0 + g->rows);
     return OFX_OK;
+}
+
+// ---- roctx ranges around the session's stages (tracing) ------------------------------------------------------
+// `rocprofv3 --marker-trace` shows them next to the kernels, so a timeline of a frame loop needs no custom tracer.  The marker
+// library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so) the first time a range is opened with
+// OFX_ROCTX=1 in the environment: no link dependency, and nothing at all -- one load of a static flag -- when the variable is
+// not set.
+namespace {
+typedef int (*roctx_push_fn)(const char *);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_push = nullptr;
+roctx_pop_fn g_pop = nullptr;
+bool roctx_on()
+{
+    static const bool on = [] {
+        const char *e = getenv("OFX_ROCTX");
+        if (!e || atoi(e) <= 0) return false;
+        for (const char *name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                g_push = reinterpret_cast<roctx_push_fn>(dlsym(h, "roctxRangePushA"));
+                g_pop = reinterpret_cast<roctx_pop_fn>(dlsym(h, "roctxRangePop"));
+                if (g_push && g_pop) return true;
+            }
+        }
+        return false;
+    }();
+    return on;
+}
+} // namespace
+
+void ofx_range_push(const char *name)
+{
+    if (roctx_on()) (void)g_push(name);
+}
+void ofx_range_pop(void)
+{
+    if (roctx_on()) (void)g_pop();
 }

@@ -36,6 +36,16 @@ static inline hipStream_t ofx_stream(void *s) { return reinterpret_cast<hipStrea
 
 static inline int ofx_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// roctx range around a stage of the session (ofx_core.cpp; active with OFX_ROCTX=1, see there)
+void ofx_range_push(const char *name);
+void ofx_range_pop(void);
+struct OfxRange {
+    explicit OfxRange(const char *name) { ofx_range_push(name); }
+    ~OfxRange() { ofx_range_pop(); }
+    OfxRange(const OfxRange &) = delete;
+    OfxRange &operator=(const OfxRange &) = delete;
+};
+
 // validates the parts of an ofx_geom every kernel relies on
 int ofx_check_geom(const ofx_geom *g, const char *who);
 

@@ -92,6 +92,9 @@ struct ofx_session {
 template <typename F>
 static int timed_launch(ofx_session *s, int kind, void *stream, F &&launch)
 {
+    static const char *const names[OFX_TIME_KINDS] = {"ofx.lk_levels", "ofx.lk_levels_accumulate", "ofx.warp_levels", "ofx.stream_tick",
+                                                      "ofx.shift_levels", "ofx.corner_flows", "ofx.pyramid"};
+    OfxRange range(names[kind]); // (roctx, OFX_ROCTX=1: the launch's enqueue on the host side of a --marker-trace timeline)
     const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
     if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
     OFX_TRY(launch());

@@ -45,7 +45,9 @@ class ShardPlan:
     rank: int
     world: int
     margin: int = 8  # rows of slack for the reference's global shift (|v| <= margin keeps the shift exact)
-    halo_mode: str = "recompute"  # "recompute": halos rebuilt from a wider level-0 halo; "exchange": fetched from the neighbours
+    # "recompute": halos rebuilt from a wider level-0 halo; "exchange": fetched from the neighbours at every level;
+    # "stream_exchange": the ranges of "recompute" -- only level-0 rows ever cross ranks (ShardedFlow.assemble_frames)
+    halo_mode: str = "recompute"
     # refinement iterations (extension, ofx_params.iters): iteration j is computed on (radius + 1) * (iters - j) rows beyond the
     # block, so that the warp of iteration j + 1 finds the flow of every row it needs without a neighbour; the warp itself may
     # reach `warp_margin` rows further (|scale * v| + 1 <= warp_margin keeps it exact; the session reports when it did not)
@@ -95,8 +97,15 @@ class ShardPlan:
                 if self.world > 1 and rows < halo:
                     raise ValueError(f"level {k}: a rank owns {rows} rows, fewer than the halo of {halo}: its neighbours would need rows "
                                      "from two ranks away (use fewer ranks or the recompute mode)")
-        elif self.halo_mode != "recompute":
+        elif self.halo_mode not in ("recompute", "stream_exchange"):
             raise ValueError(f"halo_mode {self.halo_mode!r}")
+
+    def patch_wh(self, patch_size: int = 0) -> Tuple[int, int]:
+        """(width, height) of the top-left patch the corner chain reads at level 0: ofx_session_create's rule."""
+        step = 1 << (self.levels - 1)
+        side = patch_size if patch_size > 0 else max(256, step * (self.window // 2 + 2 + 8))
+        side = -(-side // step) * step
+        return min(side, self.width), min(side, self.height)
 
     def redundancy(self) -> float:
         """Fraction of extra level-0 rows held beyond the owned block (the price of exchanging nothing per level)."""
@@ -189,7 +198,9 @@ class ShardedFlow:
     def __init__(self, width, height, levels, window, mode, rank, world, device=0, margin=8, backend=None, pipelined=True,
                  corner="broadcast", patch_size=0, stream_batch=1, halo_mode="recompute", borrow_frames=False, iters=1):
         assert corner in ("broadcast", "local")
-        assert halo_mode == "recompute" or corner == "broadcast", "the exchange mode is pair-at-a-time (rank 0's corner + broadcast)"
+        assert halo_mode in ("recompute", "stream_exchange") or corner == "broadcast", "the exchange mode is pair-at-a-time (rank 0's corner + broadcast)"
+        assert halo_mode != "stream_exchange" or corner == "local", "stream_exchange: every rank forms the shift vectors from the patch rows it receives"
+        self.patch_size = patch_size
         assert iters <= 1 or corner == "local", "refinement iterations on a sharded pair run through the stream pipeline (corner='local')"
         self.plan = ShardPlan(width, height, levels, window, rank, world, margin, halo_mode, iters=iters)
         self.rank, self.world, self.pipelined, self.corner = rank, world, pipelined, corner
@@ -212,6 +223,95 @@ class ShardedFlow:
 
     def stream_drain(self) -> int:
         return self.session.stream_drain()
+
+    # ---- frames that ARRIVE sharded, through the stream pipeline (halo_mode == "stream_exchange") ------------------------------
+    # north_star's "RCCL halo exchange" for callers whose ranks only ever receive their own rows of a frame, without giving up
+    # the one-launch pipeline: what crosses ranks is LEVEL 0 only -- the halo rows this rank's plan holds beyond its block (the
+    # halos of the coarser levels are recomputed from them, as in "recompute"), and the rows / columns of the frame's top-left
+    # patch, from which every rank forms the shift vectors itself -- one batched group of sends and receives per TICK of B frames,
+    # issued for the next tick while the launch of this one runs.  The session then sees an ordinary frame buffer in which the rows
+    # it never reads were never written.
+    def _exchange_lists(self):
+        """[(peer, row0, row1, cols)] to receive and to send: full-width halo rows and the patch's rows and columns"""
+        if getattr(self, "_xlists", None) is not None:
+            return self._xlists
+        p = self.plan
+        pw, ph = p.patch_wh(self.patch_size)
+        plans = [ShardPlan(p.width, p.height, p.levels, p.window, r, self.world, p.margin, p.halo_mode, iters=p.iters, warp_margin=p.warp_margin)
+                 for r in range(self.world)]
+
+        def wants(me, src):   # pieces of src's own rows that rank `me` needs: [(row0, row1, cols)]
+            (b0, b1), (o0, o1) = plans[me].buf[0], plans[src].own[0]
+            out = []
+            a, b = max(b0, o0), min(b1, o1)
+            if a < b:
+                out.append((a, b, p.width))
+            for a, b in ((max(0, o0), min(ph, o1, b0)), (max(o0, b1, 0), min(ph, o1))):   # patch rows outside what `me` holds anyway
+                if a < b:
+                    out.append((a, b, pw))
+            return out
+        recv = [(r,) + piece for r in range(self.world) if r != self.rank for piece in wants(self.rank, r)]
+        send = [(r,) + piece for r in range(self.world) if r != self.rank for piece in wants(r, self.rank)]
+        self._xlists = (recv, send)
+        return self._xlists
+
+    def assemble_frames(self, own_rows, buffers):
+        """own_rows[i]: this rank's rows [own0, own1) of frame i (tensor [rows, width]); buffers[i]: a frame-shaped tensor
+        [height, >= width] that receives them, the halo rows and the patch.  One batched group of P2P operations for all
+        frames (RCCL over xGMI on GPUs, gloo in the CPU tests).  Rows the plan does not hold are left untouched."""
+        import torch.distributed as dist
+
+        p = self.plan
+        o0, o1 = p.own[0]
+        recv, send = self._exchange_lists()
+        ops, keep = [], []
+        for rows, buf in zip(own_rows, buffers):
+            assert tuple(rows.shape) == (o1 - o0, p.width), (tuple(rows.shape), (o1 - o0, p.width))
+            buf[o0:o1, :p.width] = rows
+            if self.world == 1:
+                continue
+            for peer, a, b, cols in send:
+                ops.append(dist.P2POp(dist.isend, rows[a - o0: b - o0, :cols].contiguous(), peer))
+            for peer, a, b, cols in recv:
+                t = rows.new_empty((b - a, cols))
+                ops.append(dist.P2POp(dist.irecv, t, peer))
+                keep.append((buf, a, b, cols, t))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+        for buf, a, b, cols, t in keep:
+            buf[a:b, :cols] = t
+
+    def _frame_buffers(self, n, like):
+        """a ring of frame-shaped buffers for the assembled frames (borrowed frames stay in use for several ticks)"""
+        if not hasattr(self, "_ring"):
+            self._ring, self._ring_i = [], 0
+        need = 4 * max(n, 1) + 2
+        while len(self._ring) < need:
+            self._ring.append(like.new_zeros((self.plan.height, self.plan.width)))
+        out = [self._ring[(self._ring_i + i) % len(self._ring)] for i in range(n)]
+        self._ring_i = (self._ring_i + n) % len(self._ring)
+        return out
+
+    def stream_submit_own_rows(self, own_rows) -> int:
+        """A tick's frames as this rank's own rows only: assemble (exchange) and submit to the stream pipeline."""
+        bufs = self._frame_buffers(len(own_rows), own_rows[0])
+        self.assemble_frames(own_rows, bufs)
+        done = -1
+        for b in bufs:
+            done = max(done, self.session.stream_submit(b))
+        return done
+
+    def push_own_rows(self, rows):
+        """pair-at-a-time form (the CPU stand-in of the tests): priming with this rank's own rows of the first frame"""
+        (buf,) = self._frame_buffers(1, rows)
+        self.assemble_frames([rows], [buf])
+        self.push_frame(buf)
+
+    def step_own_rows(self, rows):
+        (buf,) = self._frame_buffers(1, rows)
+        self.assemble_frames([rows], [buf])
+        self.step(buf)
 
     def push_frame(self, frame):
         """Make `frame` the previous frame (priming, main.cu:203-209)."""

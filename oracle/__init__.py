@@ -24,7 +24,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(_HERE, "liboracle.so")
+# OFX_ORACLE_SO: another build of the same restatement (liboracle_ubsan.so, `make -C oracle ubsan`)
+ORACLE_SO = os.path.join(_HERE, os.environ.get("OFX_ORACLE_SO", "liboracle.so"))
 REF_SO = os.path.join(_HERE, "_ref", "libref_cpu.so")
 
 _u8p = C.POINTER(C.c_uint8)

@@ -602,6 +602,40 @@ def test_sharded_stream_sessions_with_local_corner(eng, cfg):
         s.close()
 
 
+@pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, 4, 2, False), (1920, 1088, 5, 7, 8, 4, True), (640, 480, 3, 5, 3, 1, True)])
+def test_sharded_stream_sessions_read_only_their_rows_and_the_patch(eng, cfg):
+    """ShardedFlow's "stream_exchange" mode hands a rank frame buffers in which only its level-0 buffer rows (own + halo) and
+    the frame's top-left patch were ever written (parallel.py, assemble_frames: that is all that crosses ranks).  Here R
+    logical ranks on one device get exactly such buffers -- everything else poisoned -- through the stream pipeline (copied and
+    borrowed frames): every pair must equal the unsharded plain sequence bit for bit, i.e. the session reads nothing else."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, R, B, borrow = cfg
+    nf = 3 * B + 2
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=23)[1]).cuda() for i in range(nf)]
+    want = _plain_sequence(eng, frames, w, h, L, win)
+    plans = [ShardPlan(w, h, L, win, r, R, halo_mode="stream_exchange") for r in range(R)]
+    got = {}
+    for r, pl in enumerate(plans):
+        pw, ph = pl.patch_wh(0)
+        b0, b1 = pl.buf[0]
+        bufs = []
+        for f in frames:
+            t = torch.full((h, w), 0xEE, dtype=torch.uint8, device="cuda")
+            t[b0:b1] = f[b0:b1]
+            t[:ph, :pw] = f[:ph, :pw]
+            bufs.append(t)
+        s = eng.Session(w, h, L, win, "lk_float", shard=pl, local_corner=True, stream_batch=B, borrow_frames=borrow)
+        got[r] = _stream_all_pairs(s, bufs, L, B)
+        assert s.corner_status() == 0
+        s.close()
+    for p in range(1, nf):
+        for k in range(L):
+            full = np.concatenate([got[r][p][k] for r in range(R)], axis=0)
+            assert_same(full, want[p][k], f"{R} ranks, pair {p} level {k}")
+
+
 def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     """ofx_session_corner_status must say exactly when a corner shift needed pixels the patch does not hold.  Pixel 0's
     flow is normally tiny (the zero border dominates its gradients), so the frames are a dark-cornered ramp whose

@@ -125,3 +125,21 @@ def test_float_sum_order_tolerance(oracle):
         exact = oracle.srm_1ch_f32(a, b, 19, 19, exact=True)
         bound = oracle.srm_1ch_f32(np.abs(a), np.abs(b), 19, 19, exact=True) * (361 * 2.0 ** -24)
         assert (np.abs(ordered.astype(np.float64) - exact.astype(np.float64)) <= bound + 1e-6).all()
+
+
+def test_oracle_goldens_under_ubsan():
+    """The restatement rebuilt with -fsanitize=undefined -fno-sanitize-recover=all (`make -C oracle ubsan`) runs every golden test
+    of this file in a child process: one report of undefined behaviour aborts that process.  (The reference has some on this
+    path -- uninitialised reads, float -> int of huge values, OptFlowCPU.cpp:268-269 -- which the restatement reaches the same
+    results without.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "ubsan"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, OFX_ORACLE_SO="liboracle_ubsan.so", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k", "golden and not ubsan"],
+                       env=env, cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "passed" in r.stdout

@@ -249,10 +249,25 @@ def _rank_main(rank, world, port, cfg, mode, corner="broadcast", halo_mode="reco
             f[o0:o1] = frame[o0:o1]
             return f
 
-        sf.push_frame(seen_by_rank(frames[0]))
+        import torch
+
+        def own_rows(frame):   # stream_exchange: all a rank is ever given of a frame
+            o0, o1 = plan.own[0]
+            return torch.from_numpy(frame[o0:o1].copy())
+
+        if halo_mode == "stream_exchange":
+            sf._frame_buffers(1, own_rows(frames[0]))
+            for b in sf._ring:
+                b.fill_(0xEE)   # whatever the exchange does not bring stays poison
+            sf.push_own_rows(own_rows(frames[0]))
+        else:
+            sf.push_frame(seen_by_rank(frames[0]))
         orc = Oracle()
         for i in (1, 2):
-            sf.step(seen_by_rank(frames[i]), check_margin=corner == "broadcast")
+            if halo_mode == "stream_exchange":
+                sf.step_own_rows(own_rows(frames[i]))
+            else:
+                sf.step(seen_by_rank(frames[i]), check_margin=corner == "broadcast")
             want, _, _ = orc.flow_pair(synth.to_3ch(frames[i - 1]), synth.to_3ch(frames[i]), L, win, mode, exact_sums=True)
             for k in range(L):
                 got = sf.gather_flow(k).numpy()
@@ -291,6 +306,41 @@ def test_sharded_flow_gloo_halo_exchange(world, mode):
 
     cfg = (96, 288, 3, 5, 4)  # 72 coarse rows: every rank owns >= the halo (3 + 4) rows at every level, also with 3 ranks
     mp.spawn(_rank_main, args=(world, _free_port(), cfg, mode, "broadcast", "exchange"), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+def test_sharded_flow_gloo_stream_exchange(world, mode):
+    """halo_mode="stream_exchange": a rank is given ONLY its own rows of each frame; one batched group of sends / receives per
+    frame brings the level-0 halo rows of its plan and the rows / columns of the frame's top-left patch (from which it forms the
+    shift vectors itself); the halos of the coarser levels are recomputed.  Everything else in its frame buffer is poison.
+    Bit-exact against the unsharded oracle -- the form in which sharded arrivals run the one-launch stream pipeline."""
+    import torch.multiprocessing as mp
+
+    cfg = (96, 144, 3, 5, 8)
+    mp.spawn(_rank_main, args=(world, _free_port(), cfg, mode, "local", "stream_exchange"), nprocs=world, join=True)
+
+
+def test_stream_exchange_lists_cover_the_plan():
+    """what a rank receives = exactly the rows of its level-0 buffer it does not own + the patch rows outside that buffer, each
+    from the rank that owns them; what it sends mirrors what the others receive"""
+    for (w, h, L, win, world) in ((3840, 2160, 5, 9, 8), (1920, 1080, 4, 7, 4), (96, 144, 3, 5, 3)):
+        flows = [ShardedFlow(w, h, L, win, "lk_float", r, world, backend=object(), corner="local", halo_mode="stream_exchange") for r in range(world)]
+        lists = [f._exchange_lists() for f in flows]
+        for me in range(world):
+            p = flows[me].plan
+            pw, ph = p.patch_wh(0)
+            got = np.zeros((h, w), bool)
+            got[p.own[0][0]:p.own[0][1]] = True
+            for peer, a, b, cols in lists[me][0]:
+                src = flows[peer].plan.own[0]
+                assert src[0] <= a < b <= src[1], "a piece must come from the rank that owns it"
+                assert not got[a:b, :cols].any(), "nothing is received twice"
+                got[a:b, :cols] = True
+                assert (me, a, b, cols) in [(q, x, y, c) for q, x, y, c in lists[peer][1]], "every receive has its send"
+            b0, b1 = p.buf[0]
+            assert got[b0:b1].all() and got[:ph, :pw].all(), "the level-0 buffer rows and the patch are complete"
+            assert sum(len(l[0]) for l in lists) == sum(len(l[1]) for l in lists)
 
 
 def test_exchange_plan_invariants():
