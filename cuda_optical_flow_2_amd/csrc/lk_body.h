@@ -21,6 +21,11 @@ struct LkArgs {
     int strip_h, tiles_x;
     int accumulate; // non-zero: flow += result (refinement iterations) instead of flow = result
     float min_det;  // > 0: determinant guard of the solve (lk_solve.h); <= 0: the reference
+    // refinement iterations (lk_body_buf.h, ITER == 2): the march also writes warp_out = warp(warp_src, warp_scale * new flow), the
+    // image the next iteration reads as `next`
+    const uint8_t *warp_src;
+    uint8_t *warp_out;
+    float warp_scale;
 };
 
 // one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b
@@ -1049,6 +1054,7 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
 
 
 } // namespace ofx_dev
+#include "lk_body_warp.h" // the warp of lk_iter in two stages (ITER == 2 below)
 #include "lk_body_buf.h" // lk_wave_buf: the same march on buffer resources (a fifth of the scalar instructions)
 namespace ofx_dev {
 

@@ -55,7 +55,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 constexpr int kLkDmaRowBytes = 256, kLkDmaRows = 6, kLkDmaSetBytes = kLkDmaRows * kLkDmaRowBytes;
 constexpr int kLkWaveLdsDma = kLkWaveLds + 2 * kLkDmaSetBytes; // the exchange row, then two sets of fetched rows
 
-template <int R, int MODE, bool FAST, bool INTERIOR, bool DMA>
+// ITER (refinement iterations of lk_iter): 0 = flow = result (the reference's level); 1 = flow += result,
+// the row's old flow fetched through the flow's own resource with the step's rows; 2 = the same, and the march also writes the
+// warped image the NEXT iteration reads (lk_body_warp.h): the row's new flow is in registers after the add, the warp's first stage
+// runs there and issues its tap loads, the second stage and the row's store follow one step later (whole levels only: lk_level.hip).
+template <int R, int MODE, bool FAST, bool INTERIOR, bool DMA, int ITER = 0>
 __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
@@ -113,6 +117,24 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     const bool ragged = __any(st_lo2 || st_hi2) != 0; // a level of odd width ends inside a chunk: that lane stores one pixel
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
     const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
+    // ITER >= 1: where this lane's pixels lie in a flow row (kOob: outside the image -- reads 0, is never stored)
+    [[maybe_unused]] uint32_t nat_off[4] = {0u, 0u, 0u, 0u};
+    if constexpr (ITER >= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nat_off[j] = (INTERIOR || ((cb + j) >= 0 && (cb + j) < A.w)) ? (uint32_t)(cb + j) * 8u : (uint32_t)kOob;
+    }
+    // ITER == 2: the warp source and the warped image as resources; which of this lane's pixels are output pixels of the tile
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_wsrc = rs_prev, rs_wout = rs_prev;
+    [[maybe_unused]] uint32_t wvo = (uint32_t)kOob;
+    [[maybe_unused]] WarpRowState WM;
+    if constexpr (ITER == 2) {
+        pin_scalar(A.warp_scale);
+        rs_wsrc = make_rsrc(A.warp_src, plane_bytes);
+        rs_wout = make_rsrc(A.warp_out, plane_bytes);
+        const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
+        wvo = out_lane ? (uint32_t)cb : (uint32_t)kOob; // (a level whose width is no multiple of 4 ends inside the dword: the rest is row padding)
+        warp_row_clear(WM);
+    }
 
     const int y_lim = min(min(ye + R + 1, A.h), A.row_end);
     const int y_min = max(0, A.row0);
@@ -310,6 +332,23 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             if (ro >= y_first - 1) pf_on = fetch_next(ro, po_out);
         }
         const bool emit = s >= PR;
+        // ITER >= 1: the flow this row adds to, as it lies (this lane's 4 pixels), fetched with the step's rows
+        [[maybe_unused]] f32x4 old_a, old_b;
+        if constexpr (ITER >= 1) {
+            asm("" : "=v"(old_a), "=v"(old_b));
+            if (emit) {
+                const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
+                if constexpr (INTERIOR) {
+                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off[0], fnat, 0));
+                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off[0] + 16u, fnat, 0));
+                } else { // (per pixel: a level of odd width ends inside a 16-byte piece)
+                    const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[0], fnat, 0), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[1], fnat, 0);
+                    const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[2], fnat, 0), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[3], fnat, 0);
+                    old_a = __builtin_bit_cast(f32x4, u32x4{p0.x, p0.y, p1.x, p1.y});
+                    old_b = __builtin_bit_cast(f32x4, u32x4{p2.x, p2.y, p3.x, p3.y});
+                }
+            }
+        }
 
         const uint32_t him = folded ? 0x00010000u : (yo >= y_first ? 0xffff0000u : 0u);
         uint32_t rowm = ((uint32_t)yy < (uint32_t)A.h ? 0x00000001u : 0u) | ((uint32_t)yh < (uint32_t)A.h ? him : 0u);
@@ -370,6 +409,20 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #else
             solve_lane<MODE, FAST>(hxx, hyy, hxy, hxt, hyt, sopt, uv);
 #endif
+            if constexpr (ITER >= 1) { // (the old flow is zero in the columns outside the image, which are never stored)
+                uv[0] = old_a.x + uv[0], uv[1] = old_a.y + uv[1], uv[2] = old_a.z + uv[2], uv[3] = old_a.w + uv[3];
+                uv[4] = old_b.x + uv[4], uv[5] = old_b.y + uv[5], uv[6] = old_b.z + uv[6], uv[7] = old_b.w + uv[7];
+            }
+            if constexpr (ITER == 2) {
+                // the warped row of the step before: second stage and store (nothing is pending in the first emitting step: its
+                // store goes nowhere); then this row's first stage, from the flow just formed -- its tap loads have a step to arrive
+                const int yw = yy - R; // this step's output row
+                const uint32_t wn = warp_row_finish(WM);
+                const int wso = __builtin_amdgcn_readfirstlane(s > PR ? (yw - 1 - A.row0) * A.pitch : kOob);
+                __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, wso, 0);
+                const float fu[4] = {uv[0], uv[2], uv[4], uv[6]}, fv[4] = {uv[1], uv[3], uv[5], uv[7]};
+                warp_row_prepare(rs_wsrc, A.warp_scale, A.w, A.h, A.pitch, cb, yw, fu, fv, WM);
+            }
             *(__attribute__((address_space(3))) f32x4 *)(xl_w) = f32x4{uv[0], uv[1], uv[2], uv[3]};
             *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -425,6 +478,10 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #undef OFX_LK_PRIO_STEP
     // the rows issued by the last step are never taken: they must have landed before the wave gives its LDS back
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (ITER == 2) { // the warped row of the last step
+        const uint32_t wn = warp_row_finish(WM);
+        __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, (ye - 1 - A.row0) * A.pitch, 0);
+    }
 }
 
 } // namespace ofx_dev

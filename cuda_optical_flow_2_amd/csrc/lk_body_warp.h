@@ -1,0 +1,75 @@
+// The bilinear warp of lk_iter in the form the accumulating march uses (lk_body_buf.h, ITER == 2): one
+// lane's 4 adjacent pixels of one row, in two stages with the loads of the taps in flight between them.  Included by lk_body.h.
+//
+// A refinement iteration used to be two launches: warp_u8_kernel (flow -> warped image: a flow load, then the tap loads that
+// depend on it, per short wave -- latency-bound at 0.37 of the HBM roofline) and the accumulating level kernel.  The march of
+// iteration j now also writes the warped image iteration j + 1 reads: the flow of an output row is in registers right after
+// its solve, so the row's warp needs no flow load at all, and its tap loads have a whole step of the march to arrive.  Only the
+// first refinement iteration of a pair still needs warp_u8_kernel.
+//
+// Per pixel the four taps are two (generally unaligned) dwords, one from each of the rows yi and y1, at byte xi of the row --
+// pulled back to the row's last dword where xi lies beyond it -- loaded through a buffer resource, so that no coordinate, however
+// wild, reads outside the level.  Unlike warp_u8_kernel's 3 x 8-byte window per lane this form has no condition to qualify for
+// and therefore no second, general form: eight loads per lane instead of six, fewer instructions, no call.
+// The arithmetic per pixel is the oracle's (orc_warp_bilinear_u8), in the operation order of warp4_general (stages_body.h):
+// the bytes are those of warp_u8_kernel.  A pixel whose flow is not finite is not warped (stages_body.h): here, a pixel with
+// zero flow -- both fractions are 0 then, and p + 0 * (q - p) is p for all bytes p, q.
+#pragma once
+
+namespace ofx_dev {
+
+struct WarpRowState {      // a row of a lane between the two stages
+    float fx[4], fy[4];    // the fractions of the source coordinates
+    uint32_t sel[4];       // per pixel the byte selector (xi - xb, x1 - xb, zero, zero) into its two dwords
+    uint32_t ra[4], rb[4]; // per pixel the dwords of rows yi and y1 (loads in flight between the stages)
+};
+
+__device__ __forceinline__ void warp_row_clear(WarpRowState &M)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.sel[k] = 0x0c0c0c0cu, M.ra[k] = M.rb[k] = 0u;
+}
+
+// Stage 1: source coordinates and selectors; issues the eight tap loads through `rs` (the whole level of the warp source: rows
+// [0, h), `pitch` bytes apart, pitch >= 4).
+__device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &rs, float scale, int w, int h, int pitch, int x0, int y,
+                                                 const float (&fu)[4], const float (&fv)[4], WarpRowState &M)
+{
+    const float xf0 = (float)x0, yf = (float)y, wmaxf = (float)(w - 1), hmaxf = (float)(h - 1);
+    const int wmax = w - 1, hmax = h - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xr = xf0 + (float)k;
+        const float sxr = xr + scale * fu[k], syr = yf + scale * fv[k];
+        const bool ok = __builtin_fabsf(sxr) <= 1e9f && __builtin_fabsf(syr) <= 1e9f; // (NaN fails)
+        const float sx = __builtin_amdgcn_fmed3f(ok ? sxr : xr, 0.0f, wmaxf);
+        const float sy = __builtin_amdgcn_fmed3f(ok ? syr : yf, 0.0f, hmaxf);
+        const int xi = (int)sx, yi = (int)sy;
+        M.fx[k] = __builtin_amdgcn_fractf(sx); // == sx - (float)xi: sx >= 0, the difference is exact
+        M.fy[k] = __builtin_amdgcn_fractf(sy);
+        const int xb = min(xi, pitch - 4); // the dword stays inside the row pitch
+        const uint32_t oa = (uint32_t)(yi * pitch + xb), ob = (uint32_t)(min(yi + 1, hmax) * pitch + xb);
+        M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, oa, 0, 0);
+        M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 0);
+        M.sel[k] = (uint32_t)(xi - xb) | ((uint32_t)(min(xi + 1, wmax) - xb) << 8) | 0x0c0c0000u;
+    }
+}
+
+// Stage 2: the taps have arrived; the row's four bytes.
+__device__ __forceinline__ uint32_t warp_row_finish(const WarpRowState &M)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t pa = __builtin_amdgcn_perm(0u, M.ra[k], M.sel[k]), pb = __builtin_amdgcn_perm(0u, M.rb[k], M.sel[k]);
+        const float p00 = (float)(pa & 0xffu), p01 = (float)((pa >> 8) & 0xffu);
+        const float p10 = (float)(pb & 0xffu), p11 = (float)((pb >> 8) & 0xffu);
+        const float a = p00 + M.fx[k] * (p01 - p00);
+        const float b = p10 + M.fx[k] * (p11 - p10);
+        const float v = a + M.fy[k] * (b - a);
+        out |= ((uint32_t)(int)(v + 0.5f) & 0xffu) << (8 * k);
+    }
+    return out;
+}
+
+} // namespace ofx_dev

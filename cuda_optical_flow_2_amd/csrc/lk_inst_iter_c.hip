@@ -1,0 +1,11 @@
+// One family of instantiations of the templates in lk_launch.h (see there): refinement iterations on the buffer march.
+#include "lk_launch.h"
+
+namespace ofx_launch {
+
+int iter_compat_cpu(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st)
+{
+    return warp_out ? launch_iter_mode<OFX_MODE_COMPAT_CPU, false, 2>(radius, lv, n, st) : launch_iter_mode<OFX_MODE_COMPAT_CPU, false, 1>(radius, lv, n, st);
+}
+
+} // namespace ofx_launch

@@ -53,6 +53,29 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
     lk_wave<R, MODE, SUMS, true, FAST>(T, (int)blockIdx.x, (int)threadIdx.x, xlds);
 }
 
+// A refinement iteration of lk_iter on the buffer march (lk_body_buf.h): ITER = 1 adds to the flow, ITER = 2 also writes the warped
+// image of the next iteration (lk_body_warp.h).
+#ifndef OFX_ITER_MIN_WAVES
+#define OFX_ITER_MIN_WAVES 3
+#endif
+template <int R, int MODE, bool FAST, int ITER>
+__global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES) void lk_iter_kernel(const LkTable T)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[kLkWaveLds];
+    const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (wave >= T.first_block[T.n]) return;
+    int level = 0, hi = T.n;
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (wave >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
+    const int tile = (wave - T.first_block[level]) % T.lv[level].tiles_x;
+    const int cb0 = tile * TileGeom<R>::OUT_W - TileGeom<R>::LO_LANE * 4;
+    if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true, false, ITER>(T, wave, lane, xlds);
+    else lk_wave_buf<R, MODE, FAST, false, false, ITER>(T, wave, lane, xlds);
+}
+
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
 // A tick of a frame stream runs, as disjoint block ranges of ONE grid,
 //     pyramid(newest frame(s))  |  corner flows(earlier pair(s))  |  fused LK(still earlier pair(s))
@@ -244,6 +267,17 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
     return OFX_OK;
 }
 
+template <int R, int MODE, bool FAST, int ITER>
+int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
+{
+    static const int capacity = lk_wave_target(lk_iter_kernel<R, MODE, FAST, ITER>, 64, 0, 0, 4);
+    LkTable t{};
+    const int blocks = plan_table<R>(lv, n, capacity, &t);
+    hipLaunchKernelGGL((lk_iter_kernel<R, MODE, FAST, ITER>), dim3((unsigned)blocks), dim3(64), 0, st, t);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 // Deep fetch (DMA = true) pays where a step's row loads come from HBM -- measured on MI355X (profiles/r03_ablation.txt): 8K,
 // two frames per launch: 279 vs 295 us (-5 %); 4K with its frames in the Infinity Cache: 247 vs 237 us (+4 %: the form costs
 // ~60 more scalar instructions per step, and the loads are short there) -- so it is chosen by the size of the largest level:
@@ -316,6 +350,30 @@ int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, co
     return OFX_E_UNSUPPORTED;
 }
 
+template <int MODE, bool FAST, int ITER>
+int launch_iter_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
+{
+    switch (radius) {
+    case 1: return launch_iter_r<1, MODE, FAST, ITER>(lv, n, st);
+    case 2: return launch_iter_r<2, MODE, FAST, ITER>(lv, n, st);
+    case 3: return launch_iter_r<3, MODE, FAST, ITER>(lv, n, st);
+    case 4: return launch_iter_r<4, MODE, FAST, ITER>(lv, n, st);
+    case 5: return launch_iter_r<5, MODE, FAST, ITER>(lv, n, st);
+    case 6: return launch_iter_r<6, MODE, FAST, ITER>(lv, n, st);
+    case 7: return launch_iter_r<7, MODE, FAST, ITER>(lv, n, st);
+    case 8: return launch_iter_r<8, MODE, FAST, ITER>(lv, n, st);
+    case 9: return launch_iter_r<9, MODE, FAST, ITER>(lv, n, st);
+    case 10: return launch_iter_r<10, MODE, FAST, ITER>(lv, n, st);
+    case 11: return launch_iter_r<11, MODE, FAST, ITER>(lv, n, st);
+    default: break;
+    }
+    if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
+        if (radius == 12) return launch_iter_r<12, MODE, FAST, ITER>(lv, n, st);
+    }
+    ofx_set_error("ofx_lk_level: window %d not supported in mode %d", 2 * radius + 1, MODE);
+    return OFX_E_UNSUPPORTED;
+}
+
 template <int MODE, bool SUMS, bool FAST>
 int launch_mode(int radius, const LkLevelIn *lv, int n, hipStream_t st)
 {
@@ -347,6 +405,10 @@ namespace ofx_launch {
 int levels_lk_float(int radius, const LkLevelIn *lv, int n, bool sums, hipStream_t st);
 int levels_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 int levels_compat_cpu(int radius, const LkLevelIn *lv, int n, bool sums, hipStream_t st);
+// refinement iterations on the buffer march: flow += result; warp_out: the launch also writes the next iteration's warped images
+int iter_lk_float(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
+int iter_lk_float_fast(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
+int iter_compat_cpu(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
 int stream_lk_float(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);

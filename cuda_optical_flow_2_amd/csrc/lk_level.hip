@@ -69,6 +69,18 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
         a.out_y0 = g->out_y0;
         a.out_y1 = g->out_y1;
         a.flow_row0 = d[i].flow_row0;
+        OFX_REQUIRE((d[i].d_warp_out != nullptr) == (d[0].d_warp_out != nullptr) && (d[i].accumulate != 0) == (d[0].accumulate != 0),
+                    "ofx_lk_levels: accumulate and d_warp_out must be set for all descriptors of a launch or for none");
+        if (d[i].d_warp_out) { // the launch also writes the next iteration's warped image (lk_body_warp.h)
+            OFX_REQUIRE(!d_sums && d[i].accumulate && d[i].d_warp_src, "ofx_lk_levels: d_warp_out needs accumulate and d_warp_src");
+            OFX_REQUIRE(d[i].d_warp_out != d[i].d_next && d[i].d_warp_out != d[i].d_warp_src && d[i].d_warp_out != d[i].d_prev,
+                        "ofx_lk_levels: d_warp_out must be a plane of its own");
+            OFX_REQUIRE(g->row0 == 0 && g->rows == g->h && g->out_y0 == 0 && g->out_y1 == g->h,
+                        "ofx_lk_levels: d_warp_out takes whole levels (row-sharded callers warp with ofx_warp_levels)");
+            a.warp_src = d[i].d_warp_src;
+            a.warp_out = d[i].d_warp_out;
+            a.warp_scale = d[i].warp_scale;
+        }
         lv[m].a = a;
         lv[m].rows_out = rows_out;
         ++m;
@@ -85,6 +97,21 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
     if (m == 0) return OFX_OK;
     const int radius = window >> 1;
     hipStream_t st = ofx_stream(stream);
+    if (lv[0].a.accumulate && !d_sums) {
+        // refinement iterations run on the buffer march (32-bit offsets: levels below 2 GB; larger ones keep the old form, which
+        // cannot write the warped image)
+        bool small = true;
+        for (int i = 0; i < m; ++i)
+            small = small && (size_t)(lv[i].a.row_end - lv[i].a.row0) * (size_t)lv[i].a.pitch < ((size_t)1 << 31) &&
+                    (size_t)(lv[i].a.out_y1 - lv[i].a.flow_row0) * (size_t)lv[i].a.w * 8 < ((size_t)1 << 31);
+        const bool wout = lv[0].a.warp_out != nullptr;
+        static const bool old_form = [] { const char *e = getenv("OFX_ITER_OLD_MARCH"); return e && atoi(e) != 0; }();
+        OFX_REQUIRE(small || !wout, "ofx_lk_levels: d_warp_out needs levels below 2 GB");
+        if (small && (wout || !old_form)) {
+            if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::iter_lk_float_fast(radius, lv, m, wout, st);
+            return mode == OFX_MODE_LK_FLOAT ? ofx_launch::iter_lk_float(radius, lv, m, wout, st) : ofx_launch::iter_compat_cpu(radius, lv, m, wout, st);
+        }
+    }
     if (d_sums) // the sums do not depend on the solve
         return mode != OFX_MODE_COMPAT_CPU ? ofx_launch::levels_lk_float(radius, lv, m, true, st) : ofx_launch::levels_compat_cpu(radius, lv, m, true, st);
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::levels_lk_float_fast(radius, lv, m, st);
@@ -195,7 +222,10 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     S.n_corner = g->n_corner;
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;
-    if (g->n_lk > 0) OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
+    if (g->n_lk > 0) {
+        OFX_REQUIRE(g->lk[0].d_warp_out == nullptr && !g->lk[0].accumulate, "ofx_stream_launch: a tick's LK stage is iteration 1 (no accumulate, no d_warp_out)");
+        OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
+    }
     // the stream kernel's LK stage addresses planes and flow through buffer resources with 32-bit offsets (lk_body_buf.h)
     for (int i = 0; i < m; ++i) {
         const LkArgs &a = lv[i].a;

@@ -38,7 +38,8 @@ struct ofx_session {
     uint8_t *img[kSets][OFX_MAX_LEVELS]{};              // see kSets
     uint8_t *sh[2][OFX_MAX_LEVELS]{};
     // refinement iterations in the stream pipeline: per flow set (pair p -> set p mod B) the shifted and the warped next image
-    uint8_t *itsh[kMaxBatch][2][OFX_MAX_LEVELS]{};
+    uint8_t *itsh[kMaxBatch][3][OFX_MAX_LEVELS]{};
+    bool fused_iters = false; // the accumulating launches also write the next iteration's warped image (lk_body_warp.h)
     int cur = 0, sht = 0;                               // img[cur] = previous frame, img[(cur+1)%3] = next frame
     uint8_t *plane[3][OFX_MAX_LEVELS]{};                // role view: 0 prev, 1 next, 2 shifted scratch
     hipStream_t aux = nullptr;                          // pipelined path: staging stream owned by the session
@@ -169,8 +170,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->n_sets = n_sets;
     size_t total = 0;
     // (streamed refinement iterations: two more scratch planes per pair of a tick)
-    const int n_iter_sets = p->iters > 1 ? 2 * (p->stream_batch >= 2 ? p->stream_batch : 1) : 0;
-    std::vector<size_t> off_plane[kSets + 2 + 2 * kMaxBatch], off_flow, off_flow2, flow_stride;
+    const int n_iter_sets = p->iters > 1 ? 3 * (p->stream_batch >= 2 ? p->stream_batch : 1) : 0; // per flow set: shifted, warped, warped'
+    std::vector<size_t> off_plane[kSets + 2 + 3 * kMaxBatch], off_flow, off_flow2, flow_stride;
     for (int k = 0; k < p->levels; ++k) {
         s->w[k] = p->width >> k;
         s->h[k] = p->height >> k;
@@ -302,7 +303,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     for (int k = 0; k < p->levels; ++k) {
         for (int t = 0; t < n_sets; ++t) s->img[t][k] = base + off_plane[t][k];
         for (int t = 0; t < 2; ++t) s->sh[t][k] = base + off_plane[n_sets + t][k];
-        for (int t = 0; t < n_iter_sets; ++t) s->itsh[t / 2][t % 2][k] = base + off_plane[n_sets + 2 + t][k];
+        for (int t = 0; t < n_iter_sets; ++t) s->itsh[t / 3][t % 3][k] = base + off_plane[n_sets + 2 + t][k];
         s->flowset[0][k] = reinterpret_cast<float *>(base + off_flow[k]);
         for (int t = 1; t < kMaxBatch; ++t)
             s->flowset[t][k] = reinterpret_cast<float *>(base + (t < p->stream_batch ? off_flow2[k] + (size_t)(t - 1) * flow_stride[k] : off_flow[k]));
@@ -324,6 +325,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->pair_status = s->corner_status + 1;
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = p->sharded ? nullptr : base + off_staging;
+    // whole levels only; OFX_ITER_FUSED=0 keeps one ofx_warp_levels launch per refinement iteration
+    s->fused_iters = p->iters > 1 && !p->sharded && [] { const char *e = getenv("OFX_ITER_FUSED"); return !e || atoi(e) != 0; }();
     repoint(s);
     *out = s;
     return OFX_OK;
@@ -577,15 +580,21 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
     for (int k = L - 1; k >= 0; --k)
         lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0, s->p.min_det};
     OFX_TRY(timed_lk_launch(s, lk, nl, stream));
+    // The warped image alternates between two planes (sh[1] and the iteration scratch's third): an accumulating launch reads one
+    // and, fused (lk_body_warp.h), writes the other for the iteration after it -- only iteration 2 needs the warp launch then.
+    uint8_t *const *wbuf[2] = {s->sh[1], s->itsh[0][2]};
     for (int it = 1; it < s->p.iters; ++it) {
+        const bool fused = s->fused_iters, need_warp = !fused || it == 1, wout = fused && it + 1 < s->p.iters;
+        uint8_t *const *win = fused ? wbuf[(it - 1) & 1] : s->sh[1], *const *wnext = wbuf[it & 1];
         ofx_warp_desc wd[OFX_MAX_LEVELS];
         nl = 0;
         for (int k = L - 1; k >= 0; --k) {
-            wd[nl] = ofx_warp_desc{src(k), s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE, nullptr, 0};
-            lk[nl] = ofx_lk_desc{s->plane[0][k], s->sh[1][k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1, s->p.min_det};
+            wd[nl] = ofx_warp_desc{src(k), win[k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, OFX_ITER_SCALE, nullptr, 0};
+            lk[nl] = ofx_lk_desc{s->plane[0][k], win[k], level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 1, s->p.min_det};
+            if (wout) lk[nl].d_warp_src = src(k), lk[nl].d_warp_out = wnext[k], lk[nl].warp_scale = OFX_ITER_SCALE;
             ++nl;
         }
-        OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nl, stream); }));
+        if (need_warp) OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nl, stream); }));
         OFX_TRY(timed_lk_launch(s, lk, nl, stream));
     }
     return OFX_OK;
@@ -996,6 +1005,10 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         const int reach = s->p.window / 2 + 1;
         auto clip = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
         for (int it = 1; it < s->p.iters; ++it) { // it = iterations done so far; this pass computes iteration it + 1
+            // fused (lk_body_warp.h): the accumulating launch also writes the warped images of the pass after it, into the other of
+            // the flow set's two warped planes; only the first pass needs the warp launch then
+            const bool fused = s->fused_iters, need_warp = !fused || it == 1, wout = fused && it + 1 < s->p.iters;
+            const int wi = fused ? 1 + ((it - 1) & 1) : 1, wo = 1 + (it & 1);
             int ns = 0, nw = 0;
             for (long pl = f0 - D * B; pl <= f0 - D * B + B - 1; ++pl) {
                 if (pl < 1 || pl > last_frame) continue;
@@ -1018,14 +1031,15 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                         if (it == 1) sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], level_geom(s, k, s->buf0[k], s->buf1[k]), uvslot(pl) + 2 * k};
                         src = s->itsh[b][0][k];
                     }
-                    wd[nw] = ofx_warp_desc{src, s->itsh[b][1][k], level_geom(s, k, wa, we), s->flowset[b][k], s->fl0[k], OFX_ITER_SCALE,
+                    wd[nw] = ofx_warp_desc{src, s->itsh[b][wi][k], level_geom(s, k, wa, we), s->flowset[b][k], s->fl0[k], OFX_ITER_SCALE,
                                            s->p.sharded ? s->corner_status : nullptr, 16 + k};
-                    ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][1][k], level_geom(s, k, a, e), s->flowset[b][k], s->fl0[k], nullptr, 1, s->p.min_det};
+                    ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][wi][k], level_geom(s, k, a, e), s->flowset[b][k], s->fl0[k], nullptr, 1, s->p.min_det};
+                    if (wout) ld[nw].d_warp_src = src, ld[nw].d_warp_out = s->itsh[b][wo][k], ld[nw].warp_scale = OFX_ITER_SCALE;
                     ++nw;
                 }
             }
             if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
-            OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nw, stream); }));
+            if (need_warp) OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nw, stream); }));
             OFX_TRY(timed_launch(s, OFX_TIME_LK_ACC, stream, [&] { return ofx_lk_levels(ld, nw, s->p.window, s->p.mode, stream); }));
         }
     }

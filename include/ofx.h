@@ -108,6 +108,14 @@ typedef struct ofx_lk_desc {
      * rounded to float, is below min_det gets the flow (0, 0).  0 = the reference.  One value per launch: the first
      * descriptor's. */
     float min_det;
+    /* Extension (lk_iter; csrc/lk_body_warp.h).  d_warp_out non-NULL, with accumulate set: the launch also writes the warped image
+     * the NEXT refinement iteration reads as its d_next -- d_warp_out = ofx_warp_levels(d_warp_src, the flow this launch leaves in
+     * d_flow, warp_scale), same bytes -- so that only a pair's first refinement iteration needs ofx_warp_levels.  d_warp_src is the
+     * warp source (the globally shifted next image), d_warp_out a plane of the level's geometry other than d_next and d_warp_src.
+     * Whole levels only (row0 = 0, rows = h, out rows [0, h)); for all descriptors of a launch or for none. */
+    const uint8_t *d_warp_src;
+    uint8_t *d_warp_out;
+    float warp_scale;
 } ofx_lk_desc;
 int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
 

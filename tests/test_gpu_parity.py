@@ -946,6 +946,30 @@ def test_iterative_refinement_matches_oracle(eng, oracle, cfg):
         assert_same(one[k], ref[k], f"iters=1 is the reference, L{k}")
 
 
+@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+@pytest.mark.parametrize("cfg", [(324, 204, 3, 9, 4), (640, 360, 2, 15, 3), (250, 130, 2, 5, 6), (517, 259, 1, 23, 3)])
+def test_fused_warp_of_the_next_iteration_equals_the_warp_launch(eng, monkeypatch, cfg, mode):
+    """From the second refinement iteration on, the accumulating launch of iteration j also writes the warped image iteration
+    j + 1 reads (csrc/lk_body_warp.h: per pixel two dwords of taps through a buffer resource, no general form), so only the first
+    refinement iteration runs ofx_warp_levels.  OFX_ITER_FUSED=0 keeps one warp launch per iteration: both must give the same
+    bits -- on frames that drive the warp everywhere it can go: flat blocks (the reference's unguarded solve leaves NaN / Inf
+    there: "no warp"), noise (huge finite flows: taps clamped to all four borders, neighbours far apart), odd widths (a row's
+    last dword, the ragged end of a tile), every window class of the box sums."""
+    w, h, L, win, iters = cfg
+    p, n = synth.random_pair(w, h, seed=w + win)
+    sp, sn = synth.smooth_pair(w, h, 1.5, -0.9, seed=w)
+    p[: h // 2], n[: h // 2] = sp[: h // 2], sn[: h // 2]          # smooth texture above, noise below
+    p[h // 3: h // 3 + 40, w // 4: w // 4 + 90] = 77                # a flat block in both frames: 0 / 0 in its windows
+    n[h // 3: h // 3 + 40, w // 4: w // 4 + 90] = 77
+    monkeypatch.setenv("OFX_ITER_FUSED", "0")
+    want = eng.flow_pair(p, n, L, win, mode, iters=iters)
+    monkeypatch.setenv("OFX_ITER_FUSED", "1")
+    got = eng.flow_pair(p, n, L, win, mode, iters=iters)
+    assert not np.isfinite(want[0]).all(), "the frames were meant to produce non-finite flows"
+    for k in range(L):
+        assert_same(got[k], want[k], f"{mode} {w}x{h} win {win} iters {iters}: level {k}")
+
+
 def test_iterative_refinement_converges_to_the_translation(eng):
     """Known answer: a smooth texture translated by (0.6,-0.4) px.  Flow is in the reference's units (15/8 of a pixel,
     SURVEY 8a row 10); refinement must move the median estimate closer to the truth than the single reference pass."""
