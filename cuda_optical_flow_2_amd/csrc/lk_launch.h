@@ -408,7 +408,6 @@ int levels_compat_cpu(int radius, const LkLevelIn *lv, int n, bool sums, hipStre
 // refinement iterations on the buffer march: flow += result; warp_out: the launch also writes the next iteration's warped images
 int iter_lk_float(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
 int iter_lk_float_fast(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
-int iter_compat_cpu(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
 int stream_lk_float(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);

@@ -106,11 +106,9 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
                     (size_t)(lv[i].a.out_y1 - lv[i].a.flow_row0) * (size_t)lv[i].a.w * 8 < ((size_t)1 << 31);
         const bool wout = lv[0].a.warp_out != nullptr;
         static const bool old_form = [] { const char *e = getenv("OFX_ITER_OLD_MARCH"); return e && atoi(e) != 0; }();
-        OFX_REQUIRE(small || !wout, "ofx_lk_levels: d_warp_out needs levels below 2 GB");
-        if (small && (wout || !old_form)) {
-            if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::iter_lk_float_fast(radius, lv, m, wout, st);
-            return mode == OFX_MODE_LK_FLOAT ? ofx_launch::iter_lk_float(radius, lv, m, wout, st) : ofx_launch::iter_compat_cpu(radius, lv, m, wout, st);
-        }
+        OFX_REQUIRE(!wout || (small && mode != OFX_MODE_COMPAT_CPU), "ofx_lk_levels: d_warp_out needs mode lk_float and levels below 2 GB");
+        if (small && (wout || !old_form) && mode != OFX_MODE_COMPAT_CPU) // (compat_cpu accumulates in the old form below)
+            return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::iter_lk_float_fast(radius, lv, m, wout, st) : ofx_launch::iter_lk_float(radius, lv, m, wout, st);
     }
     if (d_sums) // the sums do not depend on the solve
         return mode != OFX_MODE_COMPAT_CPU ? ofx_launch::levels_lk_float(radius, lv, m, true, st) : ofx_launch::levels_compat_cpu(radius, lv, m, true, st);

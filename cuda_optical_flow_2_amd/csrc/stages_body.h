@@ -305,8 +305,12 @@ struct ShiftTable { // (level, pair) items: up to the levels of every pair of a 
 __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int tid)
 {
     if (blk >= T.first_block[T.n]) return;
-    int level = 0;
-    while (level + 1 < T.n && blk >= T.first_block[level + 1]) ++level;
+    int level = 0, hi = T.n; // (binary search: a linear scan is a chain of dependent scalar loads, ~20 items deep in a stream tick)
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (blk >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
     const ShiftArgs &A = T.lv[level];
     const int block = blk - T.first_block[level];
     const int bx = block % A.blocks_x, by = block / A.blocks_x;
@@ -477,8 +481,12 @@ __device__ __forceinline__ uint32_t warp4_general(const WarpArgs &A, int x0, int
 __device__ __forceinline__ void warp_block(const WarpTable &T, int blk, int tid)
 {
     if (blk >= T.first_block[T.n]) return;
-    int level = 0;
-    while (level + 1 < T.n && blk >= T.first_block[level + 1]) ++level;
+    int level = 0, hi = T.n; // (binary search: a linear scan is a chain of dependent scalar loads, ~20 items deep in a stream tick)
+    while (hi - level > 1) {
+        const int mid = (level + hi) >> 1;
+        if (blk >= T.first_block[mid]) level = mid;
+        else hi = mid;
+    }
     const WarpArgs &A = T.lv[level];
     const int block = blk - T.first_block[level];
     const int bx = block % A.blocks_x, by = block / A.blocks_x;

@@ -946,7 +946,7 @@ def test_iterative_refinement_matches_oracle(eng, oracle, cfg):
         assert_same(one[k], ref[k], f"iters=1 is the reference, L{k}")
 
 
-@pytest.mark.parametrize("mode", ["lk_float", "compat_cpu"])
+@pytest.mark.parametrize("mode", ["lk_float", "lk_float_fast"])
 @pytest.mark.parametrize("cfg", [(324, 204, 3, 9, 4), (640, 360, 2, 15, 3), (250, 130, 2, 5, 6), (517, 259, 1, 23, 3)])
 def test_fused_warp_of_the_next_iteration_equals_the_warp_launch(eng, monkeypatch, cfg, mode):
     """From the second refinement iteration on, the accumulating launch of iteration j also writes the warped image iteration
