@@ -64,6 +64,21 @@ def iters_pair_bytes(w, h, levels, iters, rows=None):
     return (LK_BYTES_PER_PX + (iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
 
 
+def iters_pair_bytes_fused(w, h, levels, iters, rows=None):
+    """the same pair counted for the launches as they run since round 3 (SURVEY 8d's rule: every array once per stage): the
+    accumulating launch of iteration j also writes the warped image of iteration j + 1 (csrc/lk_body_warp.h: prev 1 + warped 1
+    + warp source 1 + flow 8 read, flow 8 + warped' 1 written = 20 B/px), so only iteration 2 has a warp launch (10 B/px) and
+    the last iteration writes no image (18 B/px)"""
+    px = level_px(w, h, levels, rows)
+    extra = 0 if iters <= 1 else WARP_BYTES_PER_PX + (iters - 2) * (LK_ACC_BYTES_PER_PX + 2) + LK_ACC_BYTES_PER_PX
+    return (LK_BYTES_PER_PX + extra) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
+
+
+ITERS_ACCOUNTING = ("frac counts 28 B/px per extra iteration (a warp pass + an accumulating pass: the accounting of rounds 1-2, kept so that "
+                    "the figures stay comparable); frac_as_launched counts the launches as they run now -- 20 B/px per fused iteration, one "
+                    "warp pass per pair")
+
+
 def roofline_block(nbytes, us, **more):
     gbs = nbytes / (us * 1e-6) / 1e9 if us else 0.0
     out = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4)}
@@ -571,8 +586,10 @@ class Run:
                 # refinement iterations: the roofline is that of the whole pair -- every launch event-timed and tagged
                 kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
                 us_pair = sum(v[0] * v[2] for v in kk.values() if v[2]) / (ticks * batch)
-                nbytes = iters_pair_bytes(w2, h2, l2, iters)
+                nbytes, nfused = iters_pair_bytes(w2, h2, l2, iters), iters_pair_bytes_fused(w2, h2, l2, iters)
                 res["roofline"] = roofline_block(nbytes, us_pair, algorithmic_bytes_per_pair=nbytes, kernel_us_per_pair=round(us_pair, 2),
+                                                 frac_as_launched=round(nfused / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 algorithmic_bytes_per_pair_as_launched=nfused, accounting=ITERS_ACCOUNTING,
                                                  launches={k: {"avg_us": round(v[0], 2), "per_tick": v[2] // ticks} for k, v in kk.items() if v[2]})
             s2.timing(0)
         s2.close()
@@ -627,6 +644,8 @@ class Run:
                 "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms2, 5), "frames_per_s": round(1e3 / ms2, 1),
                 "pairs_timed": n2,
                 "roofline": roofline_block(pair_alg, kernel_us, algorithmic_bytes_per_pair=pair_alg, kernel_us_per_pair=round(kernel_us, 2),
+                                           frac_as_launched=round(iters_pair_bytes_fused(w, h, levels, it) / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                           algorithmic_bytes_per_pair_as_launched=iters_pair_bytes_fused(w, h, levels, it), accounting=ITERS_ACCOUNTING,
                                            launches=launches, timed_in="second pass, hipEventRecord around every launch of the pair")}
 
     def leg_baseline_config(self, name, steps):
@@ -644,7 +663,9 @@ class Run:
         r1 = self.stream_leg(wl, self.args.mode, b1, True, ring1, steps, two_stage=two1)
         r1["workload"] = f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters=1, stream path, {b1} frames per launch"
         out["iters1"] = r1
-        bi = 4 if 4 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 3840 * 2160 else 2
+        # (pairs per launch for the iterations: 8 where the items fit -- 4K: 28.2k vs 27.4k Mpix/s at 4 since the accumulating
+        # launches write the next iteration's warped images; 8K: 2)
+        bi = 16 if 16 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 1920 * 1080 else (8 if 8 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 3840 * 2160 else 2)
         ringi = ring1 if len(ring1) >= 3 * bi + 1 else self.device_ring(wl, bi, False)
         ri = self.stream_leg(wl, self.args.mode, bi, True, ringi, steps, two_stage=False, iters=it, min_launches=12 if w2 * h2 <= 3840 * 2160 else 6)
         ri["workload"] = (f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters={it} (extension lk_iter), streamed: {bi} pairs per "
@@ -935,7 +956,10 @@ class Run:
             # and tagged (ofx_session_timing_read_kind)
             pair_alg = iters_pair_bytes(w, h, levels, args.iters, own_rows)
             us_pair = sum(v[0] * v[2] for v in self.kinds.values() if v[2]) / (self.roof_steps * fps)
+            fused_alg = iters_pair_bytes_fused(w, h, levels, args.iters, own_rows)
             iters_pair = {"algorithmic_bytes_per_pair": pair_alg, "kernel_us_per_pair": round(us_pair, 2),
+                          "frac_as_launched": round(fused_alg / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if driver is None else None,
+                          "algorithmic_bytes_per_pair_as_launched": fused_alg if driver is None else None, "accounting": ITERS_ACCOUNTING,
                           "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in self.kinds.items() if v[2]}}
             lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, self.roof_steps
         achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0

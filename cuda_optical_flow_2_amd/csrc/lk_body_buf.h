@@ -117,12 +117,9 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     const bool ragged = __any(st_lo2 || st_hi2) != 0; // a level of odd width ends inside a chunk: that lane stores one pixel
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
     const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
-    // ITER >= 1: where this lane's pixels lie in a flow row (kOob: outside the image -- reads 0, is never stored)
-    [[maybe_unused]] uint32_t nat_off[4] = {0u, 0u, 0u, 0u};
-    if constexpr (ITER >= 1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) nat_off[j] = (INTERIOR || ((cb + j) >= 0 && (cb + j) < A.w)) ? (uint32_t)(cb + j) * 8u : (uint32_t)kOob;
-    }
+    // ITER >= 1: where this lane's pixels lie in a flow row (the byte offset of the first; pixels outside the image get kOob
+    // from their column mask when the row is fetched: they read 0 and are never stored)
+    [[maybe_unused]] uint32_t nat_off = (uint32_t)cb * 8u;
     // ITER == 2: the warp source and the warped image as resources; which of this lane's pixels are output pixels of the tile
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_wsrc = rs_prev, rs_wout = rs_prev;
     [[maybe_unused]] uint32_t wvo = (uint32_t)kOob;
@@ -339,11 +336,12 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             if (emit) {
                 const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
                 if constexpr (INTERIOR) {
-                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off[0], fnat, 0));
-                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off[0] + 16u, fnat, 0));
+                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off, fnat, 0));
+                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off + 16u, fnat, 0));
                 } else { // (per pixel: a level of odd width ends inside a 16-byte piece)
-                    const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[0], fnat, 0), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[1], fnat, 0);
-                    const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[2], fnat, 0), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, nat_off[3], fnat, 0);
+                    auto off = [&](int j) { return cm[j] ? nat_off + 8u * (uint32_t)j : (uint32_t)kOob; };
+                    const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(0), fnat, 0), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(1), fnat, 0);
+                    const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(2), fnat, 0), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(3), fnat, 0);
                     old_a = __builtin_bit_cast(f32x4, u32x4{p0.x, p0.y, p1.x, p1.y});
                     old_b = __builtin_bit_cast(f32x4, u32x4{p2.x, p2.y, p3.x, p3.y});
                 }

@@ -55,11 +55,14 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 
 // A refinement iteration of lk_iter on the buffer march (lk_body_buf.h): ITER = 1 adds to the flow, ITER = 2 also writes the warped
 // image of the next iteration (lk_body_warp.h).
+// ITER = 2 needs 126 VGPRs in interior tiles and 130 in the tiles at the image's left and right edge (128 for 9x9: four waves per
+// SIMD, three for the other windows).  Capping it at 128 everywhere spills 2-8 registers and measured 1-3 % slower at 1080p, 4K
+// and 8K (profiles/r03_ablation.txt), so the cap stays at three waves.
 #ifndef OFX_ITER_MIN_WAVES
-#define OFX_ITER_MIN_WAVES 3
+#define OFX_ITER_MIN_WAVES(ITER) 3
 #endif
 template <int R, int MODE, bool FAST, int ITER>
-__global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES) void lk_iter_kernel(const LkTable T)
+__global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
 {
     __shared__ __attribute__((aligned(16))) uint8_t xlds[kLkWaveLds];
     const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
