@@ -553,7 +553,7 @@ class Run:
         torch, engine = self.torch, self.engine
         w2, h2, l2, win2 = wl
         two_stage = (self.args.two_stage and borrow) if two_stage is None else two_stage   # like the main run wherever the frames are borrowed
-        two_stage = bool(two_stage and iters <= 1)
+        two_stage = bool(two_stage and iters <= 1)   # (with iterations the tick is a quarter of a pair's time; two stages measured no gain)
         assert len(ring) >= (2 if two_stage else 3) * batch + 1 or not borrow, "the ring is too short for borrowed frames"
         s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage, iters=iters)
         s2.stream_begin()
