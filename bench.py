@@ -65,18 +65,18 @@ def iters_pair_bytes(w, h, levels, iters, rows=None):
 
 
 def iters_pair_bytes_fused(w, h, levels, iters, rows=None):
-    """the same pair counted for the launches as they run since round 3 (SURVEY 8d's rule: every array once per stage): the
-    accumulating launch of iteration j also writes the warped image of iteration j + 1 (csrc/lk_body_warp.h: prev 1 + warped 1
-    + warp source 1 + flow 8 read, flow 8 + warped' 1 written = 20 B/px), so only iteration 2 has a warp launch (10 B/px) and
-    the last iteration writes no image (18 B/px)"""
+    """the same pair counted for the launches as they run since round 3 (SURVEY 8d's rule: every array once per stage): every
+    launch but the last also writes the warped image of the iteration after it (csrc/lk_body_warp.h) -- iteration 1: 10 B/px +
+    warp source 1 read + warped 1 written; iterations 2 .. n-1: prev 1 + warped 1 + warp source 1 + flow 8 read, flow 8 + warped' 1
+    written = 20 B/px; the last iteration writes no image (18 B/px); there is no warp pass"""
     px = level_px(w, h, levels, rows)
-    extra = 0 if iters <= 1 else WARP_BYTES_PER_PX + (iters - 2) * (LK_ACC_BYTES_PER_PX + 2) + LK_ACC_BYTES_PER_PX
+    extra = 0 if iters <= 1 else 2 + (iters - 2) * (LK_ACC_BYTES_PER_PX + 2) + LK_ACC_BYTES_PER_PX
     return (LK_BYTES_PER_PX + extra) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
 
 
 ITERS_ACCOUNTING = ("frac counts 28 B/px per extra iteration (a warp pass + an accumulating pass: the accounting of rounds 1-2, kept so that "
-                    "the figures stay comparable); frac_as_launched counts the launches as they run now -- 20 B/px per fused iteration, one "
-                    "warp pass per pair")
+                    "the figures stay comparable); frac_as_launched counts the launches as they run now -- 20 B/px per iteration that also "
+                    "writes the next one's warped image, 18 for the last, no warp pass")
 
 
 def roofline_block(nbytes, us, **more):

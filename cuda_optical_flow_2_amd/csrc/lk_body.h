@@ -1061,7 +1061,8 @@ namespace ofx_dev {
 // One wave of the fused level kernel: picks the variant for its tile (wave-uniform: two complete copies of the march, nothing
 // merges after them).
 // LDS_ROWS: xlds holds kLkWaveLdsDma bytes and the march fetches its rows through LDS (lk_body_buf.h, DMA)
-template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false, bool LDS_ROWS = false>
+// ITER: lk_wave_buf's (0, or 3 = also write the warped image of the pair's second iteration); buffer march only
+template <int R, int MODE, bool SUMS, bool MAY_ACC = true, bool FAST = false, bool LDS_ROWS = false, int ITER = 0>
 __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     if (wave >= T.first_block[T.n]) return;
@@ -1075,10 +1076,10 @@ __device__ __forceinline__ void lk_wave(const LkTable &T, int wave, int lane, ui
     const int cb0 = tile * TileGeom<R>::OUT_W - TileGeom<R>::LO_LANE * 4;
     if constexpr (OFX_LK_BUFFER_PATH && !SUMS && !MAY_ACC) { // (the host keeps levels of 2 GB and more out of such launches)
 #if OFX_LK_INTERIOR_VARIANT
-        if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true, LDS_ROWS>(T, wave, lane, xlds);
+        if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true, LDS_ROWS, ITER>(T, wave, lane, xlds);
         else
 #endif
-            lk_wave_buf<R, MODE, FAST, false, LDS_ROWS>(T, wave, lane, xlds);
+            lk_wave_buf<R, MODE, FAST, false, LDS_ROWS, ITER>(T, wave, lane, xlds);
         return;
     }
 #if OFX_LK_INTERIOR_VARIANT

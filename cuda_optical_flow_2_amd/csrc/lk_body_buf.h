@@ -58,12 +58,14 @@ constexpr int kLkWaveLdsDma = kLkWaveLds + 2 * kLkDmaSetBytes; // the exchange r
 // ITER (refinement iterations of lk_iter): 0 = flow = result (the reference's level); 1 = flow += result,
 // the row's old flow fetched through the flow's own resource with the step's rows; 2 = the same, and the march also writes the
 // warped image the NEXT iteration reads (lk_body_warp.h): the row's new flow is in registers after the add, the warp's first stage
-// runs there and issues its tap loads, the second stage and the row's store follow one step later (whole levels only: lk_level.hip).
+// runs there and issues its tap loads, the second stage and the row's store follow one step later (whole levels only: lk_level.hip);
+// 3 = iteration 1 of a pair that has more: flow = result, and the warped image of iteration 2.
 template <int R, int MODE, bool FAST, bool INTERIOR, bool DMA, int ITER = 0>
 __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
+    constexpr bool ACC = ITER == 1 || ITER == 2, WOUT = ITER >= 2;
 
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
@@ -117,14 +119,14 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     const bool ragged = __any(st_lo2 || st_hi2) != 0; // a level of odd width ends inside a chunk: that lane stores one pixel
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
     const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
-    // ITER >= 1: where this lane's pixels lie in a flow row (the byte offset of the first; pixels outside the image get kOob
+    // ACC: where this lane's pixels lie in a flow row (the byte offset of the first; pixels outside the image get kOob
     // from their column mask when the row is fetched: they read 0 and are never stored)
     [[maybe_unused]] uint32_t nat_off = (uint32_t)cb * 8u;
-    // ITER == 2: the warp source and the warped image as resources; which of this lane's pixels are output pixels of the tile
+    // WOUT: the warp source and the warped image as resources; which of this lane's pixels are output pixels of the tile
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_wsrc = rs_prev, rs_wout = rs_prev;
     [[maybe_unused]] uint32_t wvo = (uint32_t)kOob;
     [[maybe_unused]] WarpRowState WM;
-    if constexpr (ITER == 2) {
+    if constexpr (WOUT) {
         pin_scalar(A.warp_scale);
         rs_wsrc = make_rsrc(A.warp_src, plane_bytes);
         rs_wout = make_rsrc(A.warp_out, plane_bytes);
@@ -329,9 +331,9 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             if (ro >= y_first - 1) pf_on = fetch_next(ro, po_out);
         }
         const bool emit = s >= PR;
-        // ITER >= 1: the flow this row adds to, as it lies (this lane's 4 pixels), fetched with the step's rows
+        // ACC: the flow this row adds to, as it lies (this lane's 4 pixels), fetched with the step's rows
         [[maybe_unused]] f32x4 old_a, old_b;
-        if constexpr (ITER >= 1) {
+        if constexpr (ACC) {
             asm("" : "=v"(old_a), "=v"(old_b));
             if (emit) {
                 const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
@@ -407,11 +409,11 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #else
             solve_lane<MODE, FAST>(hxx, hyy, hxy, hxt, hyt, sopt, uv);
 #endif
-            if constexpr (ITER >= 1) { // (the old flow is zero in the columns outside the image, which are never stored)
+            if constexpr (ACC) { // (the old flow is zero in the columns outside the image, which are never stored)
                 uv[0] = old_a.x + uv[0], uv[1] = old_a.y + uv[1], uv[2] = old_a.z + uv[2], uv[3] = old_a.w + uv[3];
                 uv[4] = old_b.x + uv[4], uv[5] = old_b.y + uv[5], uv[6] = old_b.z + uv[6], uv[7] = old_b.w + uv[7];
             }
-            if constexpr (ITER == 2) {
+            if constexpr (WOUT) {
                 // the warped row of the step before: second stage and store (nothing is pending in the first emitting step: its
                 // store goes nowhere); then this row's first stage, from the flow just formed -- its tap loads have a step to arrive
                 const int yw = yy - R; // this step's output row
@@ -476,7 +478,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #undef OFX_LK_PRIO_STEP
     // the rows issued by the last step are never taken: they must have landed before the wave gives its LDS back
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if constexpr (ITER == 2) { // the warped row of the last step
+    if constexpr (WOUT) { // the warped row of the last step
         const uint32_t wn = warp_row_finish(WM);
         __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, (ye - 1 - A.row0) * A.pitch, 0);
     }

@@ -108,8 +108,10 @@ using ofx_launch::g_trace_header;
 #define OFX_STREAM_MIN_BLOCKS(R, MODE) ((MODE) == OFX_MODE_LK_FLOAT ? 5 : 4)
 #endif
 // DMA: the LK stage fetches its rows two steps ahead through LDS (lk_body_buf.h); chosen per launch by launch_stream_r
-template <int R, int MODE, bool FAST, bool DMA>
-__global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
+// WOUT: the LK stage is iteration 1 of pairs that have more (lk_iter): it also writes the warped images of their second iteration
+// (lk_body_buf.h, ITER = 3; ~128 VGPRs: three blocks per CU at least)
+template <int R, int MODE, bool FAST, bool DMA, bool WOUT = false>
+__global__ __launch_bounds__(256, WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256, OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_ke
                                      reinterpret_cast<int *>(lds + kCornerScratch - 32));
         }
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false, FAST, DMA>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
+        lk_wave<R, MODE, false, false, FAST, DMA, WOUT ? 3 : 0>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -285,14 +287,14 @@ int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
 // two frames per launch: 279 vs 295 us (-5 %); 4K with its frames in the Infinity Cache: 247 vs 237 us (+4 %: the form costs
 // ~60 more scalar instructions per step, and the loads are short there) -- so it is chosen by the size of the largest level:
 // planes of 16 Mpx and more do not stay cached between their two uses.  OFX_LK_DMA=0 / 1 overrides.
-template <int R, int MODE, bool FAST, bool DMA>
+template <int R, int MODE, bool FAST, bool DMA, bool WOUT>
 int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     constexpr size_t wave_lds = DMA ? kLkWaveLdsDma : kLkWaveLds;
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
     // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
-    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA>, 256, 4 * wave_lds, 1, 2);
-    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA>, 256, 4 * wave_lds, 1, 4);
+    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT>, 256, 4 * wave_lds, 1, 2);
+    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT>, 256, 4 * wave_lds, 1, 4);
     int pairs = 0;
     for (int i = 0; i < n; ++i) pairs += (lv[i].a.w == lv[0].a.w && lv[i].a.h == lv[0].a.h) ? 1 : 0;
     const int capacity = pairs >= 2 ? capacity2 : capacity1;
@@ -312,42 +314,42 @@ int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage
     }
     if (lds < corner_lds) lds = corner_lds;
     if (lds < 4 * wave_lds) lds = 4 * wave_lds; // an LK block: four waves, each with its exchange row (and its fetched rows)
-    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST, DMA>), dim3((unsigned)blocks), dim3(256), lds, st, S);
+    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST, DMA, WOUT>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
 
-template <int R, int MODE, bool FAST>
+template <int R, int MODE, bool FAST, bool WOUT>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
 #if OFX_LK_BUFFER_PATH && OFX_LK_DMA_ROWS
     static const int forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
     long max_px = 0;
     for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
-    if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true>(lv, n, S, stage_blocks, lds, st);
+    if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true, WOUT>(lv, n, S, stage_blocks, lds, st);
 #endif
-    return launch_stream_rd<R, MODE, FAST, false>(lv, n, S, stage_blocks, lds, st);
+    return launch_stream_rd<R, MODE, FAST, false, WOUT>(lv, n, S, stage_blocks, lds, st);
 }
 
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, bool WOUT = false>
 int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     switch (radius) {
-    case 1: return launch_stream_r<1, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 2: return launch_stream_r<2, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 3: return launch_stream_r<3, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 4: return launch_stream_r<4, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 5: return launch_stream_r<5, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 6: return launch_stream_r<6, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 7: return launch_stream_r<7, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 8: return launch_stream_r<8, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 9: return launch_stream_r<9, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 10: return launch_stream_r<10, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
-    case 11: return launch_stream_r<11, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+    case 1: return launch_stream_r<1, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 2: return launch_stream_r<2, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 3: return launch_stream_r<3, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 4: return launch_stream_r<4, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 5: return launch_stream_r<5, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 6: return launch_stream_r<6, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 7: return launch_stream_r<7, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 8: return launch_stream_r<8, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 9: return launch_stream_r<9, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 10: return launch_stream_r<10, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
+    case 11: return launch_stream_r<11, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
     default: break;
     }
     if constexpr (MODE == OFX_MODE_COMPAT_CPU) {
-        if (radius == 12) return launch_stream_r<12, MODE, FAST>(lv, n, S, stage_blocks, lds, st);
+        if (radius == 12) return launch_stream_r<12, MODE, FAST, WOUT>(lv, n, S, stage_blocks, lds, st);
     }
     ofx_set_error("ofx_stream_launch: window %d not supported in mode %d", 2 * radius + 1, MODE);
     return OFX_E_UNSUPPORTED;
@@ -408,9 +410,13 @@ namespace ofx_launch {
 int levels_lk_float(int radius, const LkLevelIn *lv, int n, bool sums, hipStream_t st);
 int levels_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 int levels_compat_cpu(int radius, const LkLevelIn *lv, int n, bool sums, hipStream_t st);
-// refinement iterations on the buffer march: flow += result; warp_out: the launch also writes the next iteration's warped images
-int iter_lk_float(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
-int iter_lk_float_fast(int radius, const LkLevelIn *lv, int n, bool warp_out, hipStream_t st);
+// refinement iterations on the buffer march (lk_wave_buf's ITER): 1 flow += result; 2 the launch also writes the next iteration's
+// warped images; 3 iteration 1 of pairs that have more: flow = result and the warped images of iteration 2
+int iter_lk_float(int radius, const LkLevelIn *lv, int n, int iter, hipStream_t st);
+int iter_lk_float_fast(int radius, const LkLevelIn *lv, int n, int iter, hipStream_t st);
+// a tick whose LK stage also writes the warped images of its pairs' second iteration
+int stream_lk_float_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
+int stream_lk_float_fast_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);

@@ -72,7 +72,7 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
         OFX_REQUIRE((d[i].d_warp_out != nullptr) == (d[0].d_warp_out != nullptr) && (d[i].accumulate != 0) == (d[0].accumulate != 0),
                     "ofx_lk_levels: accumulate and d_warp_out must be set for all descriptors of a launch or for none");
         if (d[i].d_warp_out) { // the launch also writes the next iteration's warped image (lk_body_warp.h)
-            OFX_REQUIRE(!d_sums && d[i].accumulate && d[i].d_warp_src, "ofx_lk_levels: d_warp_out needs accumulate and d_warp_src");
+            OFX_REQUIRE(!d_sums && d[i].d_warp_src && d[i].d_flow, "ofx_lk_levels: d_warp_out needs d_warp_src and d_flow");
             OFX_REQUIRE(d[i].d_warp_out != d[i].d_next && d[i].d_warp_out != d[i].d_warp_src && d[i].d_warp_out != d[i].d_prev,
                         "ofx_lk_levels: d_warp_out must be a plane of its own");
             OFX_REQUIRE(g->row0 == 0 && g->rows == g->h && g->out_y0 == 0 && g->out_y1 == g->h,
@@ -97,7 +97,7 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
     if (m == 0) return OFX_OK;
     const int radius = window >> 1;
     hipStream_t st = ofx_stream(stream);
-    if (lv[0].a.accumulate && !d_sums) {
+    if ((lv[0].a.accumulate || lv[0].a.warp_out) && !d_sums) {
         // refinement iterations run on the buffer march (32-bit offsets: levels below 2 GB; larger ones keep the old form, which
         // cannot write the warped image)
         bool small = true;
@@ -107,8 +107,9 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
         const bool wout = lv[0].a.warp_out != nullptr;
         static const bool old_form = [] { const char *e = getenv("OFX_ITER_OLD_MARCH"); return e && atoi(e) != 0; }();
         OFX_REQUIRE(!wout || (small && mode != OFX_MODE_COMPAT_CPU), "ofx_lk_levels: d_warp_out needs mode lk_float and levels below 2 GB");
+        const int iter = wout ? (lv[0].a.accumulate ? 2 : 3) : 1; // (lk_wave_buf's ITER)
         if (small && (wout || !old_form) && mode != OFX_MODE_COMPAT_CPU) // (compat_cpu accumulates in the old form below)
-            return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::iter_lk_float_fast(radius, lv, m, wout, st) : ofx_launch::iter_lk_float(radius, lv, m, wout, st);
+            return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::iter_lk_float_fast(radius, lv, m, iter, st) : ofx_launch::iter_lk_float(radius, lv, m, iter, st);
     }
     if (d_sums) // the sums do not depend on the solve
         return mode != OFX_MODE_COMPAT_CPU ? ofx_launch::levels_lk_float(radius, lv, m, true, st) : ofx_launch::levels_compat_cpu(radius, lv, m, true, st);
@@ -221,7 +222,8 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
     int m = 0;
     if (g->n_lk > 0) {
-        OFX_REQUIRE(g->lk[0].d_warp_out == nullptr && !g->lk[0].accumulate, "ofx_stream_launch: a tick's LK stage is iteration 1 (no accumulate, no d_warp_out)");
+        OFX_REQUIRE(!g->lk[0].accumulate, "ofx_stream_launch: a tick's LK stage is iteration 1 (no accumulate)");
+        OFX_REQUIRE(g->lk[0].d_warp_out == nullptr || mode != OFX_MODE_COMPAT_CPU, "ofx_stream_launch: d_warp_out needs mode lk_float");
         OFX_TRY(lk_build_levels(g->lk, g->n_lk, window, mode, nullptr, lv, &m));
     }
     // the stream kernel's LK stage addresses planes and flow through buffer resources with 32-bit offsets (lk_body_buf.h)
@@ -233,6 +235,9 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     }
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
+    if (m > 0 && lv[0].a.warp_out) // the LK stage also writes the warped images of its pairs' second iteration (levels below 2 GB: checked above)
+        return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::stream_lk_float_fast_wout(window >> 1, lv, m, S, stage_blocks, lds, st)
+                                              : ofx_launch::stream_lk_float_wout(window >> 1, lv, m, S, stage_blocks, lds, st);
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::stream_lk_float_fast(window >> 1, lv, m, S, stage_blocks, lds, st);
     return mode == OFX_MODE_LK_FLOAT ? ofx_launch::stream_lk_float(window >> 1, lv, m, S, stage_blocks, lds, st)
                                      : ofx_launch::stream_compat_cpu(window >> 1, lv, m, S, stage_blocks, lds, st);

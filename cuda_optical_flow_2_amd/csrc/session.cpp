@@ -576,15 +576,18 @@ static int lk_all_levels(ofx_session *s, const float *uv, void *stream)
         sd[ns++] = ofx_shift_desc{s->plane[1][k], s->sh[0][k], level_geom(s, k, 0, s->h[k]), uv + 2 * k};
     if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
     auto src = [&](int k) { return k == L - 1 ? s->plane[1][k] : s->sh[0][k]; };
-    int nl = 0;
-    for (int k = L - 1; k >= 0; --k)
-        lk[nl++] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0, s->p.min_det};
-    OFX_TRY(timed_lk_launch(s, lk, nl, stream));
-    // The warped image alternates between two planes (sh[1] and the iteration scratch's third): an accumulating launch reads one
-    // and, fused (lk_body_warp.h), writes the other for the iteration after it -- only iteration 2 needs the warp launch then.
+    // The warped image alternates between two planes (sh[1] and the iteration scratch's third): fused (lk_body_warp.h), every launch
+    // but the last writes the warped image the iteration after it reads, from the flow it has in registers -- no warp launch at all.
     uint8_t *const *wbuf[2] = {s->sh[1], s->itsh[0][2]};
+    int nl = 0;
+    for (int k = L - 1; k >= 0; --k) {
+        lk[nl] = ofx_lk_desc{s->plane[0][k], src(k), level_geom(s, k, 0, s->h[k]), s->flow[k], 0, nullptr, 0, s->p.min_det};
+        if (s->fused_iters) lk[nl].d_warp_src = src(k), lk[nl].d_warp_out = wbuf[0][k], lk[nl].warp_scale = OFX_ITER_SCALE;
+        ++nl;
+    }
+    OFX_TRY(timed_lk_launch(s, lk, nl, stream));
     for (int it = 1; it < s->p.iters; ++it) {
-        const bool fused = s->fused_iters, need_warp = !fused || it == 1, wout = fused && it + 1 < s->p.iters;
+        const bool fused = s->fused_iters, need_warp = !fused, wout = fused && it + 1 < s->p.iters;
         uint8_t *const *win = fused ? wbuf[(it - 1) & 1] : s->sh[1], *const *wnext = wbuf[it & 1];
         ofx_warp_desc wd[OFX_MAX_LEVELS];
         nl = 0;
@@ -964,16 +967,37 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         }
     }
     long newest = -1;
+    static thread_local ofx_shift_desc sd0[OFX_MAX_LK_ITEMS];
+    int ns0 = 0;
     for (long pl = f0 - D * B; pl <= f0 - D * B + B - 1; ++pl) { // LK(pair pl), reading next through the shift vectors the previous tick wrote
         if (pl < 1 || pl > last_frame) continue;
-        float *const *fl = s->flowset[pl % B];
+        const int b = (int)(pl % B);
+        float *const *fl = s->flowset[b];
+        if (s->fused_iters)
+            OFX_REQUIRE(!s->p.borrow_frames || (pitch_of(pl, 0, false) == s->pitch[0] && pitch_of(pl - 1, 0, false) == s->pitch[0]),
+                        "ofx_session_stream_submit: with refinement iterations borrowed frames need a row pitch of %d bytes (the "
+                        "width rounded up to 64), got %d", s->pitch[0], pitch_of(pl, 0, false));
         for (int k = L - 1; k >= 0; --k) {
             ofx_geom lg = level_geom(s, k, s->fl0[k], s->fl1[k]); // (the own rows, unless iterations follow on a shard)
             lg.pitch = pitch_of(pl, k, false);
-            g.lk[g.n_lk++] = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->fl0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0, s->p.min_det};
+            ofx_lk_desc &d = g.lk[g.n_lk++];
+            d = ofx_lk_desc{plane_of(pl - 1, k), plane_of(pl, k), lg, fl[k], s->fl0[k], k == L - 1 ? nullptr : uvslot(pl) + 2 * k, 0, s->p.min_det};
+            if (s->fused_iters) {
+                // refinement iterations follow (lk_body_warp.h): the LK stage is iteration 1 of the pair and also writes the warped
+                // image of iteration 2, so the globally shifted next image (the warp's source) is made BEFORE the tick -- its
+                // vectors are a tick old -- and the LK stage reads it as it is instead of shifting on the fly
+                const uint8_t *src = d.d_next;
+                if (k != L - 1) {
+                    sd0[ns0++] = ofx_shift_desc{d.d_next, s->itsh[b][0][k], level_geom(s, k, s->buf0[k], s->buf1[k]), uvslot(pl) + 2 * k};
+                    src = s->itsh[b][0][k];
+                }
+                d.d_next = src, d.d_uv = nullptr;
+                d.d_warp_src = src, d.d_warp_out = s->itsh[b][1][k], d.warp_scale = OFX_ITER_SCALE;
+            }
         }
         newest = pl;
     }
+    if (ns0) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd0, ns0, stream); }));
     *completed_pair = -1;
     if (newest > s->reported) {
         *completed_pair = (int)newest;
@@ -1005,9 +1029,9 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         const int reach = s->p.window / 2 + 1;
         auto clip = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
         for (int it = 1; it < s->p.iters; ++it) { // it = iterations done so far; this pass computes iteration it + 1
-            // fused (lk_body_warp.h): the accumulating launch also writes the warped images of the pass after it, into the other of
-            // the flow set's two warped planes; only the first pass needs the warp launch then
-            const bool fused = s->fused_iters, need_warp = !fused || it == 1, wout = fused && it + 1 < s->p.iters;
+            // fused (lk_body_warp.h): every launch but the last also writes the warped images of the pass after it, into the other of
+            // the flow set's two warped planes (the tick's LK stage wrote those of this loop's first pass): no warp launch
+            const bool fused = s->fused_iters, need_warp = !fused, wout = fused && it + 1 < s->p.iters;
             const int wi = fused ? 1 + ((it - 1) & 1) : 1, wo = 1 + (it & 1);
             int ns = 0, nw = 0;
             for (long pl = f0 - D * B; pl <= f0 - D * B + B - 1; ++pl) {
@@ -1028,7 +1052,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                     const uint8_t *src = next_k;
                     if (k != L - 1) {
                         // the globally shifted next image, every row the buffers hold (once per pair, before iteration 2)
-                        if (it == 1) sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], level_geom(s, k, s->buf0[k], s->buf1[k]), uvslot(pl) + 2 * k};
+                        if (it == 1 && !fused) sd[ns++] = ofx_shift_desc{next_k, s->itsh[b][0][k], level_geom(s, k, s->buf0[k], s->buf1[k]), uvslot(pl) + 2 * k};
                         src = s->itsh[b][0][k];
                     }
                     wd[nw] = ofx_warp_desc{src, s->itsh[b][wi][k], level_geom(s, k, wa, we), s->flowset[b][k], s->fl0[k], OFX_ITER_SCALE,

@@ -133,14 +133,18 @@ def test_broadcast_mode_reports_a_shift_beyond_the_halo(eng):
         b.session.close()
 
 
-def test_timing_kinds_cover_every_launch_of_a_pair(eng):
-    """ofx_session_timing tags every launch of the plain path; iters > 1 adds the shift, warp and accumulating launches."""
+def test_timing_kinds_cover_every_launch_of_a_pair(eng, monkeypatch):
+    """ofx_session_timing tags every launch of the plain path; iters > 1 adds the shift and the accumulating launches -- and no warp
+    launch: every launch but the last writes the warped image of the iteration after it (csrc/lk_body_warp.h); OFX_ITER_FUSED=0
+    keeps one warp launch per refinement iteration."""
     import torch
 
     w, h, L, win = 640, 480, 3, 9
     p, n = synth.smooth_pair(w, h, 1.0, 0.5)
-    for iters, want in ((1, {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 0, "warp": 0, "shift": 0}),
-                        (3, {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "warp": 2, "shift": 1})):
+    for iters, fused, want in ((1, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 0, "warp": 0, "shift": 0}),
+                               (3, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "warp": 0, "shift": 1}),
+                               (3, "0", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "warp": 2, "shift": 1})):
+        monkeypatch.setenv("OFX_ITER_FUSED", fused)
         s = eng.Session(w, h, L, win, "lk_float", iters=iters)
         s.push_frame_host(p)
         s.timing(16)
