@@ -783,7 +783,7 @@ class Run:
         # lk_iter extension here, next to the reference-defined line above (same process, same frames)
         it = BASELINE_ITERS[args.workload]
         lit = self.leg_iters_pair_at_a_time(wl, it, self.d_frames, args.steps)
-        b9 = 4 if 4 * levels <= MAX_LK_ITEMS else 2
+        b9 = 8 if 8 * levels <= MAX_LK_ITEMS and w * h <= 3840 * 2160 else (4 if 4 * levels <= MAX_LK_ITEMS else 2)   # (4K: 8 pairs per launch +2.6 % over 4)
         streamed = self.stream_leg(wl, args.mode, b9, args.borrow, self.d_ring if len(self.d_ring) >= 3 * b9 + 1 else make_ring(self.d_frames, ring_size(b9, False)),
                                    args.steps, two_stage=False, iters=it, min_launches=12)
         streamed["workload"] = f"as above through the stream pipeline, {b9} pairs per launch, frames " + ("read in place" if args.borrow else "copied")
