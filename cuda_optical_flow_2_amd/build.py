@@ -20,7 +20,7 @@ OBJ = os.path.join(PKG, "csrc", "_obj" + os.environ.get("OFX_BUILD_TAG", ""))
 ARCH = "gfx950"
 
 SOURCES = ["lk_inst_stream_fw.hip", "lk_inst_stream_fastw.hip", "lk_inst_stream_f.hip", "lk_inst_stream_fast.hip", "lk_inst_stream_c.hip", "lk_inst_levels_f.hip", "lk_inst_levels_fast.hip",
-           "lk_inst_levels_c.hip", "lk_inst_iter_f.hip", "lk_inst_iter_fast.hip", "lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp",
+           "lk_inst_levels_c.hip", "lk_inst_iter_f2.hip", "lk_inst_iter_fast2.hip", "lk_inst_iter_f3.hip", "lk_inst_iter_fast3.hip", "lk_inst_iter_f1.hip", "lk_inst_iter_fast1.hip", "lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "ofx_core.cpp", "session.cpp",
            "compat_gpu.cpp", "compat_cpu.cpp", "compat_stage.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and
@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s + ".o") for s in srcs]
     if force or jobs or _stale(OUT, objs):
-        cmd = [cc, "-shared", "-fPIC", "-pthread", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-ldl"]
+        cmd = [cc, "-shared", "-fPIC", "-pthread", "-Wl,--no-undefined", f"--offload-arch={ARCH}", "-o", OUT] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)

@@ -363,8 +363,14 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (DMA) {
                 // this step's rows have arrived once at most the younger loads (the next step's four or six) are outstanding
-                if (__builtin_expect(all_in, 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                // (WOUT: an emitting step has also issued the eight tap loads of its row's warp since)
+                if (WOUT && emit) {
+                    if (__builtin_expect(all_in, 1)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                } else {
+                    if (__builtin_expect(all_in, 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                }
                 const lds_ptr rp = (lds_ptr)(uintptr_t)(dma_lane + (uint32_t)((s & 1) * kLkDmaSetBytes));
                 auto row = [&](int i) { return *(const __attribute__((address_space(3))) uint32_t *)(rp + i * kLkDmaRowBytes); };
                 const uint32_t a_p = row(0), a_po = row(1), a_n = row(2), a_no = row(3);

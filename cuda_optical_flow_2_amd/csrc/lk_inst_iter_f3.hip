@@ -1,0 +1,8 @@
+// One family of instantiations of the templates in lk_launch.h (see there): refinement iterations on the buffer march, ITER = 3.
+#include "lk_launch.h"
+
+namespace ofx_launch {
+
+int iter3_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st) { return launch_iter_mode<OFX_MODE_LK_FLOAT, false, 3>(radius, lv, n, st); }
+
+} // namespace ofx_launch

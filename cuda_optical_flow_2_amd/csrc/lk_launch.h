@@ -61,10 +61,11 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 #ifndef OFX_ITER_MIN_WAVES
 #define OFX_ITER_MIN_WAVES(ITER) 3
 #endif
-template <int R, int MODE, bool FAST, int ITER>
+// DMA: the rows are fetched two steps ahead through LDS (lk_body_buf.h; chosen per launch as for the stream kernel)
+template <int R, int MODE, bool FAST, int ITER, bool DMA = false>
 __global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t xlds[kLkWaveLds];
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[DMA ? kLkWaveLdsDma : kLkWaveLds];
     const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(c
     }
     const int tile = (wave - T.first_block[level]) % T.lv[level].tiles_x;
     const int cb0 = tile * TileGeom<R>::OUT_W - TileGeom<R>::LO_LANE * 4;
-    if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true, false, ITER>(T, wave, lane, xlds);
-    else lk_wave_buf<R, MODE, FAST, false, false, ITER>(T, wave, lane, xlds);
+    if (cb0 >= 0 && cb0 + 256 <= T.lv[level].w) lk_wave_buf<R, MODE, FAST, true, DMA, ITER>(T, wave, lane, xlds);
+    else lk_wave_buf<R, MODE, FAST, false, DMA, ITER>(T, wave, lane, xlds);
 }
 
 // ---- the stream kernel: one launch = one pipeline tick ---------------------------------------------------------------
@@ -272,15 +273,29 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
     return OFX_OK;
 }
 
+template <int R, int MODE, bool FAST, int ITER, bool DMA>
+int launch_iter_rd(const LkLevelIn *lv, int n, hipStream_t st)
+{
+    static const int capacity = lk_wave_target(lk_iter_kernel<R, MODE, FAST, ITER, DMA>, 64, 0, 0, 4);
+    LkTable t{};
+    const int blocks = plan_table<R>(lv, n, capacity, &t);
+    hipLaunchKernelGGL((lk_iter_kernel<R, MODE, FAST, ITER, DMA>), dim3((unsigned)blocks), dim3(64), 0, st, t);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 template <int R, int MODE, bool FAST, int ITER>
 int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(lk_iter_kernel<R, MODE, FAST, ITER>, 64, 0, 0, 4);
-    LkTable t{};
-    const int blocks = plan_table<R>(lv, n, capacity, &t);
-    hipLaunchKernelGGL((lk_iter_kernel<R, MODE, FAST, ITER>), dim3((unsigned)blocks), dim3(64), 0, st, t);
-    OFX_HIP(hipGetLastError());
-    return OFX_OK;
+#if OFX_LK_DMA_ROWS
+    // the deep fetch, chosen as for the stream kernel (8K, 10 iterations: 15 380 vs 15 110 Mpix/s; 4K: no difference beyond the
+    // +-1.5 % between runs -- profiles/r03_ablation.txt).  OFX_ITER_DMA=0 / 1 overrides.
+    static const int forced = [] { const char *e = getenv("OFX_ITER_DMA"); return e ? atoi(e) : -1; }();
+    long max_px = 0;
+    for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
+    if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_iter_rd<R, MODE, FAST, ITER, true>(lv, n, st);
+#endif
+    return launch_iter_rd<R, MODE, FAST, ITER, false>(lv, n, st);
 }
 
 // Deep fetch (DMA = true) pays where a step's row loads come from HBM -- measured on MI355X (profiles/r03_ablation.txt): 8K,
@@ -323,10 +338,12 @@ template <int R, int MODE, bool FAST, bool WOUT>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
 #if OFX_LK_BUFFER_PATH && OFX_LK_DMA_ROWS
-    static const int forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
-    long max_px = 0;
-    for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
-    if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true, WOUT>(lv, n, S, stage_blocks, lds, st);
+    if constexpr (!WOUT) { // (a tick that also writes warped images measured slower with it: 8K 440 vs 416 us)
+        static const int forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
+        long max_px = 0;
+        for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
+        if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true, WOUT>(lv, n, S, stage_blocks, lds, st);
+    }
 #endif
     return launch_stream_rd<R, MODE, FAST, false, WOUT>(lv, n, S, stage_blocks, lds, st);
 }
@@ -412,8 +429,13 @@ int levels_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st)
 int levels_compat_cpu(int radius, const LkLevelIn *lv, int n, bool sums, hipStream_t st);
 // refinement iterations on the buffer march (lk_wave_buf's ITER): 1 flow += result; 2 the launch also writes the next iteration's
 // warped images; 3 iteration 1 of pairs that have more: flow = result and the warped images of iteration 2
-int iter_lk_float(int radius, const LkLevelIn *lv, int n, int iter, hipStream_t st);
-int iter_lk_float_fast(int radius, const LkLevelIn *lv, int n, int iter, hipStream_t st);
+// (one translation unit per ITER: lk_inst_iter_*.hip)
+int iter1_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter2_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter3_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter1_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter2_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter3_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 // a tick whose LK stage also writes the warped images of its pairs' second iteration
 int stream_lk_float_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);

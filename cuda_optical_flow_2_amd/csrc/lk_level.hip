@@ -109,7 +109,12 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
         OFX_REQUIRE(!wout || (small && mode != OFX_MODE_COMPAT_CPU), "ofx_lk_levels: d_warp_out needs mode lk_float and levels below 2 GB");
         const int iter = wout ? (lv[0].a.accumulate ? 2 : 3) : 1; // (lk_wave_buf's ITER)
         if (small && (wout || !old_form) && mode != OFX_MODE_COMPAT_CPU) // (compat_cpu accumulates in the old form below)
-            return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::iter_lk_float_fast(radius, lv, m, iter, st) : ofx_launch::iter_lk_float(radius, lv, m, iter, st);
+        {
+            using F = int (*)(int, const LkLevelIn *, int, hipStream_t);
+            static const F tab[2][3] = {{ofx_launch::iter1_lk_float, ofx_launch::iter2_lk_float, ofx_launch::iter3_lk_float},
+                                        {ofx_launch::iter1_lk_float_fast, ofx_launch::iter2_lk_float_fast, ofx_launch::iter3_lk_float_fast}};
+            return tab[mode == OFX_MODE_LK_FLOAT_FAST][iter - 1](radius, lv, m, st);
+        }
     }
     if (d_sums) // the sums do not depend on the solve
         return mode != OFX_MODE_COMPAT_CPU ? ofx_launch::levels_lk_float(radius, lv, m, true, st) : ofx_launch::levels_compat_cpu(radius, lv, m, true, st);

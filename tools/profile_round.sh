@@ -41,19 +41,18 @@ pmc() { # name, kernel substring, skip, pmc_run args...
 pmc stream stream_kernel 3 4k stream lk_float
 pmc plain lk_level_kernel 1 4k plain lk_float
 pmc compat stream_kernel 3 4k stream compat_cpu
-pmc iters5_lk lk_level_kernel 1 4k plain lk_float 5
-pmc iters5_warp warp_u8_kernel 1 4k plain lk_float 5
+pmc iters5_lk lk_iter_kernel 1 4k plain lk_float 5
 # traffic per launch for bench.py's roofline.traffic (keys: kernel, or kernel_<mode>_iters<n> for the non-default legs)
 python - $O/summary/${TAG}_traffic_pmc.jsonl > $O/summary/traffic_latest.json <<'PY'
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
-names = ["stream_kernel", "lk_level_kernel", "stream_kernel_compat_cpu_iters1", "lk_level_kernel_lk_float_iters5", "warp_u8_kernel_lk_float_iters5"]
+names = ["stream_kernel", "lk_level_kernel", "stream_kernel_compat_cpu_iters1", "lk_level_kernel_lk_float_iters5"]
 sys.path.insert(0, ".")
 import bench
 out = {"4k": {n: r.get("bytes") for n, r in zip(names, rows)},
        "kernel_source_sha16": bench.kernel_source_hash(), "measured_at_commit": None,
        "note": "HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc in separate passes (tools/profile_round.sh, tools/pmc_parse.py); "
-               "lk_level_kernel_lk_float_iters5 is the mean over the writing launch and the four accumulating ones of a pair"}
+               "lk_level_kernel_lk_float_iters5 is the mean over the five lk_iter_kernel launches of a pair (iteration 1 and three accumulating launches that also write the next warped image, one that does not)"}
 print(json.dumps(out, indent=1))
 PY
 cat $O/summary/traffic_latest.json
