@@ -26,6 +26,8 @@ struct LkArgs {
     const uint8_t *warp_src;
     uint8_t *warp_out;
     float warp_scale;
+    int *warp_status;    // row windows (ITER 4, 5): bit warp_status_bit is set when a tap row lay outside the window (optional)
+    int warp_status_bit;
 };
 
 // one launch covers several pyramid levels: block b belongs to the last level whose first_block <= b

@@ -59,13 +59,14 @@ constexpr int kLkWaveLdsDma = kLkWaveLds + 2 * kLkDmaSetBytes; // the exchange r
 // the row's old flow fetched through the flow's own resource with the step's rows; 2 = the same, and the march also writes the
 // warped image the NEXT iteration reads (lk_body_warp.h): the row's new flow is in registers after the add, the warp's first stage
 // runs there and issues its tap loads, the second stage and the row's store follow one step later (whole levels only: lk_level.hip);
-// 3 = iteration 1 of a pair that has more: flow = result, and the warped image of iteration 2.
+// 3 = iteration 1 of a pair that has more: flow = result, and the warped image of iteration 2;
+// 4 / 5 = 2 / 3 on the row window of a shard: the planes hold rows [row0, row_end) only, a tap row outside them is reported.
 template <int R, int MODE, bool FAST, bool INTERIOR, bool DMA, int ITER = 0>
 __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane, uint8_t *xlds)
 {
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
-    constexpr bool ACC = ITER == 1 || ITER == 2, WOUT = ITER >= 2;
+    constexpr bool ACC = ITER == 1 || ITER == 2 || ITER == 4, WOUT = ITER >= 2, ROWWIN = ITER >= 4;
 
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
@@ -124,7 +125,8 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     [[maybe_unused]] uint32_t nat_off = (uint32_t)cb * 8u;
     // WOUT: the warp source and the warped image as resources; which of this lane's pixels are output pixels of the tile
     [[maybe_unused]] __amdgpu_buffer_rsrc_t rs_wsrc = rs_prev, rs_wout = rs_prev;
-    [[maybe_unused]] uint32_t wvo = (uint32_t)kOob;
+    [[maybe_unused]] uint32_t wvo = (uint32_t)kOob, wmiss = 0u;
+    [[maybe_unused]] int wnpx = 0;
     [[maybe_unused]] WarpRowState WM;
     if constexpr (WOUT) {
         pin_scalar(A.warp_scale);
@@ -132,6 +134,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         rs_wout = make_rsrc(A.warp_out, plane_bytes);
         const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
         wvo = out_lane ? (uint32_t)cb : (uint32_t)kOob; // (a level whose width is no multiple of 4 ends inside the dword: the rest is row padding)
+        wnpx = out_lane ? min(4, A.w - cb) : 0;
         warp_row_clear(WM);
     }
 
@@ -427,7 +430,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 const int wso = __builtin_amdgcn_readfirstlane(s > PR ? (yw - 1 - A.row0) * A.pitch : kOob);
                 __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, wso, 0);
                 const float fu[4] = {uv[0], uv[2], uv[4], uv[6]}, fv[4] = {uv[1], uv[3], uv[5], uv[7]};
-                warp_row_prepare(rs_wsrc, A.warp_scale, A.w, A.h, A.pitch, cb, yw, fu, fv, WM);
+                warp_row_prepare<ROWWIN>(rs_wsrc, A.warp_scale, A.w, A.h, A.pitch, A.row0, A.row_end, cb, yw, wnpx, fu, fv, WM, wmiss);
             }
             *(__attribute__((address_space(3))) f32x4 *)(xl_w) = f32x4{uv[0], uv[1], uv[2], uv[3]};
             *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
@@ -487,6 +490,9 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     if constexpr (WOUT) { // the warped row of the last step
         const uint32_t wn = warp_row_finish(WM);
         __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, (ye - 1 - A.row0) * A.pitch, 0);
+        if constexpr (ROWWIN) {
+            if (__any(wmiss != 0u) && A.warp_status != nullptr && lane == 0) atomicOr(A.warp_status, 1 << A.warp_status_bit);
+        }
     }
 }
 

@@ -30,10 +30,13 @@ __device__ __forceinline__ void warp_row_clear(WarpRowState &M)
     for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.sel[k] = 0x0c0c0c0cu, M.ra[k] = M.rb[k] = 0u;
 }
 
-// Stage 1: source coordinates and selectors; issues the eight tap loads through `rs` (the whole level of the warp source: rows
-// [0, h), `pitch` bytes apart, pitch >= 4).
-__device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &rs, float scale, int w, int h, int pitch, int x0, int y,
-                                                 const float (&fu)[4], const float (&fv)[4], WarpRowState &M)
+// Stage 1: source coordinates and selectors; issues the eight tap loads through `rs` (the rows [row0, row_end) of the warp source,
+// `pitch` bytes apart, pitch >= 4: the whole level, or -- ROWWIN -- the row window a shard holds).
+// ROWWIN: a tap row outside the window is replaced by the window's nearest row, and `miss` gets bit k set for a wanted pixel k
+// (k < npx) with a finite flow whose taps needed such a row: the caller reports it (ofx_session_corner_status, bits 16 + level).
+template <bool ROWWIN>
+__device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &rs, float scale, int w, int h, int pitch, int row0, int row_end, int x0,
+                                                 int y, int npx, const float (&fu)[4], const float (&fv)[4], WarpRowState &M, uint32_t &miss)
 {
     const float xf0 = (float)x0, yf = (float)y, wmaxf = (float)(w - 1), hmaxf = (float)(h - 1);
     const int wmax = w - 1, hmax = h - 1;
@@ -48,7 +51,13 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
         M.fx[k] = __builtin_amdgcn_fractf(sx); // == sx - (float)xi: sx >= 0, the difference is exact
         M.fy[k] = __builtin_amdgcn_fractf(sy);
         const int xb = min(xi, pitch - 4); // the dword stays inside the row pitch
-        const uint32_t oa = (uint32_t)(yi * pitch + xb), ob = (uint32_t)(min(yi + 1, hmax) * pitch + xb);
+        int ya = yi, yb = min(yi + 1, hmax);
+        if constexpr (ROWWIN) {
+            if (k < npx && ok && (ya < row0 || yb >= row_end)) miss |= 1u << k;
+            ya = min(max(ya, row0), row_end - 1) - row0;
+            yb = min(max(yb, row0), row_end - 1) - row0;
+        }
+        const uint32_t oa = (uint32_t)(ya * pitch + xb), ob = (uint32_t)(yb * pitch + xb);
         M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, oa, 0, 0);
         M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 0);
         M.sel[k] = (uint32_t)(xi - xb) | ((uint32_t)(min(xi + 1, wmax) - xb) << 8) | 0x0c0c0000u;

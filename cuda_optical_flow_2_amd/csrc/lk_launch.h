@@ -110,8 +110,8 @@ using ofx_launch::g_trace_header;
 #endif
 // DMA: the LK stage fetches its rows two steps ahead through LDS (lk_body_buf.h); chosen per launch by launch_stream_r
 // WOUT: the LK stage is iteration 1 of pairs that have more (lk_iter): it also writes the warped images of their second iteration
-// (lk_body_buf.h, ITER = 3; ~128 VGPRs: three blocks per CU at least)
-template <int R, int MODE, bool FAST, bool DMA, bool WOUT = false>
+// (lk_body_buf.h, ITER = WOUT = 3, or 5 on the row windows of a shard; ~128 VGPRs: three blocks per CU at least); 0: it does not
+template <int R, int MODE, bool FAST, bool DMA, int WOUT = 0>
 __global__ __launch_bounds__(256, WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE)) voi
                                      reinterpret_cast<int *>(lds + kCornerScratch - 32));
         }
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false, FAST, DMA, WOUT ? 3 : 0>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
+        lk_wave<R, MODE, false, false, FAST, DMA, WOUT>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -302,7 +302,7 @@ int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
 // two frames per launch: 279 vs 295 us (-5 %); 4K with its frames in the Infinity Cache: 247 vs 237 us (+4 %: the form costs
 // ~60 more scalar instructions per step, and the loads are short there) -- so it is chosen by the size of the largest level:
 // planes of 16 Mpx and more do not stay cached between their two uses.  OFX_LK_DMA=0 / 1 overrides.
-template <int R, int MODE, bool FAST, bool DMA, bool WOUT>
+template <int R, int MODE, bool FAST, bool DMA, int WOUT>
 int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     constexpr size_t wave_lds = DMA ? kLkWaveLdsDma : kLkWaveLds;
@@ -334,7 +334,7 @@ int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage
     return OFX_OK;
 }
 
-template <int R, int MODE, bool FAST, bool WOUT>
+template <int R, int MODE, bool FAST, int WOUT>
 int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
 #if OFX_LK_BUFFER_PATH && OFX_LK_DMA_ROWS
@@ -348,7 +348,7 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
     return launch_stream_rd<R, MODE, FAST, false, WOUT>(lv, n, S, stage_blocks, lds, st);
 }
 
-template <int MODE, bool FAST, bool WOUT = false>
+template <int MODE, bool FAST, int WOUT = 0>
 int launch_stream_mode(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
     switch (radius) {
@@ -436,9 +436,13 @@ int iter3_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 int iter1_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 int iter2_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 int iter3_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
+int iter4_lk_float(int radius, const LkLevelIn *lv, int n, hipStream_t st);      // (2 on the row windows of a shard)
+int iter4_lk_float_fast(int radius, const LkLevelIn *lv, int n, hipStream_t st);
 // a tick whose LK stage also writes the warped images of its pairs' second iteration
 int stream_lk_float_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast_wout(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
+int stream_lk_float_wout_rw(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);      // (row windows)
+int stream_lk_float_fast_wout_rw(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);

@@ -75,11 +75,12 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
             OFX_REQUIRE(!d_sums && d[i].d_warp_src && d[i].d_flow, "ofx_lk_levels: d_warp_out needs d_warp_src and d_flow");
             OFX_REQUIRE(d[i].d_warp_out != d[i].d_next && d[i].d_warp_out != d[i].d_warp_src && d[i].d_warp_out != d[i].d_prev,
                         "ofx_lk_levels: d_warp_out must be a plane of its own");
-            OFX_REQUIRE(g->row0 == 0 && g->rows == g->h && g->out_y0 == 0 && g->out_y1 == g->h,
-                        "ofx_lk_levels: d_warp_out takes whole levels (row-sharded callers warp with ofx_warp_levels)");
             a.warp_src = d[i].d_warp_src;
             a.warp_out = d[i].d_warp_out;
             a.warp_scale = d[i].warp_scale;
+            a.warp_status = d[i].d_warp_status;
+            a.warp_status_bit = d[i].warp_status_bit;
+            OFX_REQUIRE(a.warp_status == nullptr || (a.warp_status_bit >= 0 && a.warp_status_bit < 31), "ofx_lk_levels: bad warp_status_bit");
         }
         lv[m].a = a;
         lv[m].rows_out = rows_out;
@@ -107,12 +108,16 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
         const bool wout = lv[0].a.warp_out != nullptr;
         static const bool old_form = [] { const char *e = getenv("OFX_ITER_OLD_MARCH"); return e && atoi(e) != 0; }();
         OFX_REQUIRE(!wout || (small && mode != OFX_MODE_COMPAT_CPU), "ofx_lk_levels: d_warp_out needs mode lk_float and levels below 2 GB");
-        const int iter = wout ? (lv[0].a.accumulate ? 2 : 3) : 1; // (lk_wave_buf's ITER)
+        bool rowwin = false; // a shard's row window: the warp reports taps it cannot reach (ITER 4 / 5)
+        for (int i = 0; i < m; ++i) rowwin = rowwin || lv[i].a.row0 != 0 || lv[i].a.row_end != lv[i].a.h;
+        OFX_REQUIRE(!(wout && rowwin && !lv[0].a.accumulate), "ofx_lk_levels: iteration 1 with d_warp_out on a row window runs in the stream tick only");
+        const int iter = wout ? (lv[0].a.accumulate ? (rowwin ? 4 : 2) : 3) : 1; // (lk_wave_buf's ITER)
         if (small && (wout || !old_form) && mode != OFX_MODE_COMPAT_CPU) // (compat_cpu accumulates in the old form below)
         {
             using F = int (*)(int, const LkLevelIn *, int, hipStream_t);
-            static const F tab[2][3] = {{ofx_launch::iter1_lk_float, ofx_launch::iter2_lk_float, ofx_launch::iter3_lk_float},
-                                        {ofx_launch::iter1_lk_float_fast, ofx_launch::iter2_lk_float_fast, ofx_launch::iter3_lk_float_fast}};
+            static const F tab[2][4] = {{ofx_launch::iter1_lk_float, ofx_launch::iter2_lk_float, ofx_launch::iter3_lk_float, ofx_launch::iter4_lk_float},
+                                        {ofx_launch::iter1_lk_float_fast, ofx_launch::iter2_lk_float_fast, ofx_launch::iter3_lk_float_fast,
+                                         ofx_launch::iter4_lk_float_fast}};
             return tab[mode == OFX_MODE_LK_FLOAT_FAST][iter - 1](radius, lv, m, st);
         }
     }
@@ -240,9 +245,15 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     }
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
-    if (m > 0 && lv[0].a.warp_out) // the LK stage also writes the warped images of its pairs' second iteration (levels below 2 GB: checked above)
+    if (m > 0 && lv[0].a.warp_out) { // the LK stage also writes the warped images of its pairs' second iteration (levels below 2 GB: checked above)
+        bool rw = false; // a shard's row windows
+        for (int i = 0; i < m; ++i) rw = rw || lv[i].a.row0 != 0 || lv[i].a.row_end != lv[i].a.h;
+        if (rw)
+            return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::stream_lk_float_fast_wout_rw(window >> 1, lv, m, S, stage_blocks, lds, st)
+                                                  : ofx_launch::stream_lk_float_wout_rw(window >> 1, lv, m, S, stage_blocks, lds, st);
         return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::stream_lk_float_fast_wout(window >> 1, lv, m, S, stage_blocks, lds, st)
                                               : ofx_launch::stream_lk_float_wout(window >> 1, lv, m, S, stage_blocks, lds, st);
+    }
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::stream_lk_float_fast(window >> 1, lv, m, S, stage_blocks, lds, st);
     return mode == OFX_MODE_LK_FLOAT ? ofx_launch::stream_lk_float(window >> 1, lv, m, S, stage_blocks, lds, st)
                                      : ofx_launch::stream_compat_cpu(window >> 1, lv, m, S, stage_blocks, lds, st);

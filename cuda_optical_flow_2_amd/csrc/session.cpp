@@ -325,8 +325,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->pair_status = s->corner_status + 1;
     s->uv = reinterpret_cast<float *>(base + off_uv);
     s->staging = p->sharded ? nullptr : base + off_staging;
-    // whole levels only; OFX_ITER_FUSED=0 keeps one ofx_warp_levels launch per refinement iteration
-    s->fused_iters = p->iters > 1 && !p->sharded && [] { const char *e = getenv("OFX_ITER_FUSED"); return !e || atoi(e) != 0; }();
+    // OFX_ITER_FUSED=0 keeps one ofx_warp_levels launch per refinement iteration
+    s->fused_iters = p->iters > 1 && [] { const char *e = getenv("OFX_ITER_FUSED"); return !e || atoi(e) != 0; }();
     repoint(s);
     *out = s;
     return OFX_OK;
@@ -993,6 +993,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                 }
                 d.d_next = src, d.d_uv = nullptr;
                 d.d_warp_src = src, d.d_warp_out = s->itsh[b][1][k], d.warp_scale = OFX_ITER_SCALE;
+                if (s->p.sharded) d.d_warp_status = s->corner_status, d.warp_status_bit = 16 + k; // (a tap row beyond the halo rows)
             }
         }
         newest = pl;
@@ -1058,7 +1059,10 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
                     wd[nw] = ofx_warp_desc{src, s->itsh[b][wi][k], level_geom(s, k, wa, we), s->flowset[b][k], s->fl0[k], OFX_ITER_SCALE,
                                            s->p.sharded ? s->corner_status : nullptr, 16 + k};
                     ld[nw] = ofx_lk_desc{plane_of(pl - 1, k), s->itsh[b][wi][k], level_geom(s, k, a, e), s->flowset[b][k], s->fl0[k], nullptr, 1, s->p.min_det};
-                    if (wout) ld[nw].d_warp_src = src, ld[nw].d_warp_out = s->itsh[b][wo][k], ld[nw].warp_scale = OFX_ITER_SCALE;
+                    if (wout) {
+                        ld[nw].d_warp_src = src, ld[nw].d_warp_out = s->itsh[b][wo][k], ld[nw].warp_scale = OFX_ITER_SCALE;
+                        if (s->p.sharded) ld[nw].d_warp_status = s->corner_status, ld[nw].warp_status_bit = 16 + k;
+                    }
                     ++nw;
                 }
             }

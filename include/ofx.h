@@ -112,10 +112,14 @@ typedef struct ofx_lk_desc {
      * the NEXT refinement iteration reads as its d_next -- d_warp_out = ofx_warp_levels(d_warp_src, the flow this launch leaves in
      * d_flow, warp_scale), same bytes -- so that only a pair's first refinement iteration needs ofx_warp_levels.  d_warp_src is the
      * warp source (the globally shifted next image), d_warp_out a plane of the level's geometry other than d_next and d_warp_src.
-     * Whole levels only (row0 = 0, rows = h, out rows [0, h)); for all descriptors of a launch or for none. */
+     * For all descriptors of a launch or for none.  On a row window (a shard: geom.row0 / rows / out rows are not the whole level)
+     * d_warp_out receives the out rows, a tap row outside [row0, row0 + rows) is replaced by the nearest row held, and bit
+     * warp_status_bit of *d_warp_status (optional) is set when a pixel with a finite flow needed such a row. */
     const uint8_t *d_warp_src;
     uint8_t *d_warp_out;
     float warp_scale;
+    int *d_warp_status;
+    int warp_status_bit;
 } ofx_lk_desc;
 int ofx_lk_levels(const ofx_lk_desc *levels, int n, int window, int mode, void *stream);
 
