@@ -15,7 +15,7 @@ subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contr
                 "-I" + os.path.join(root, "include"), "-I" + csrc, "-S", "--cuda-device-only", "-o", out,
                 os.path.join(csrc, ("lk_inst_stream_" if kind == "stream" else "lk_inst_levels_") + ("c" if MODE == 0 else ("fast" if int(os.environ.get("OFX_ISA_FAST", "0")) else "f")) + ".hip")] + os.environ.get("OFX_BUILD_DEFS", "").split(), check=True, stderr=subprocess.DEVNULL)
 FAST = int(os.environ.get("OFX_ISA_FAST", "0"))   # 1: the <= 1 ulp solve instantiation
-name = f"stream_kernelILi{R}ELi{MODE}ELb{FAST}ELb{int(os.environ.get('OFX_ISA_DMA', '0'))}EEE" if kind == "stream" else f"lk_level_kernelILi{R}ELi{MODE}ELb0ELb{FAST}EEE"
+name = f"stream_kernelILi{R}ELi{MODE}ELb{FAST}ELb{int(os.environ.get('OFX_ISA_DMA', '0'))}ELi0EEE" if kind == "stream" else f"lk_level_kernelILi{R}ELi{MODE}ELb0ELb{FAST}EEE"
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_Z") and name in l.split(":")[0] and ":" in l)
 end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
