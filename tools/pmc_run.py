@@ -13,6 +13,9 @@ w, h, L, win = cfg
 p, n = synth.smooth_pair(w, h)
 TWO = path == "stream" and iters <= 1  # as bench.py runs it: borrowed frames from a ring of distinct buffers, two stages
 B = engine.suggest_stream_batch(w, h, L, None, True, TWO)
+if TWO and (B < 5 or B * w * h < 30e6):   # (bench.py's plan_stream: a short launch runs in three stages -- e.g. 8K, two frames per launch)
+    TWO = False
+    B = engine.suggest_stream_batch(w, h, L, None, True, False)
 s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters, two_stage=TWO)
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
