@@ -10,7 +10,7 @@ cd $R
 for C in "GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS" \
          "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum" "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum" "TCC_EA_WRREQ_STALL_sum TCC_EA_RDREQ_32B_sum"; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python tools/pmc_run.py "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
+  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python ${PMC_RUNNER:-tools/pmc_run.py} "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
 done
 python - "$O" "$K" <<'PY'
 import csv, glob, os, sys
