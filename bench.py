@@ -5,10 +5,15 @@ A step = one pass of the hot path over one batch of input: take the new frames' 
 their pyramids, run every pyramid level coarse->fine against the previous frames' pyramids.  That is main.cu:246-272 of the
 reference.  The stream path hands the session a tick of frames per step (one launch), the pair-at-a-time paths one pair.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k|vga] [--mode lk_float|compat_cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 4k|1080p|8k|vga] [--iters I] [--mode lk_float|compat_cpu]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME frame pair is row-sharded over the ranks
-(cuda_optical_flow_2_amd/parallel.py) -- strong scaling.
+The timed configuration is BASELINE.json's config as it is WRITTEN (4K: 5 levels, 9x9, 5 iterations, streamed); the
+reference-defined pipeline (iters = 1: the only value the reference has) is measured in the same process and reported as
+extra.reference_defined_iters1 with its own roofline (iters = 1 is the additional run).  --iters 1 times that one.
+
+N > 1: the SAME frame pairs are row-sharded over the ranks (cuda_optical_flow_2_amd/parallel.py) -- strong scaling.  Started
+either by torch.distributed.run (one rank per GPU) or plainly as `python bench.py --gpus N`, which then starts
+torch.distributed.run itself as a child process, before anything touches the GPU, and exits with its code.
 
 The line carries, besides the contract's fields: `roofline` (dominant kernel, HIP events on its stream), `self_check`
 (flows of the timed session compared with an independent plain session after the timed region; the run fails when they
@@ -58,25 +63,61 @@ def pair_bytes(w, h, levels, rows=None, pyramid=True):
     return LK_BYTES_PER_PX * sum(px) + (PYR_BYTES_PER_DST_PX * sum(px[1:]) if pyramid else 0)
 
 
-def iters_pair_bytes(w, h, levels, iters, rows=None):
-    """a pair with refinement iterations: 10 + (iters - 1) * (10 + 18) B/px + 5 B/px pyramid"""
+def iters_pair_bytes_r02(w, h, levels, iters, rows=None):
+    """the accounting of rounds 1-2 (a warp pass + an accumulating pass per extra iteration): 10 + (iters - 1) * (10 + 18) B/px +
+    5 B/px pyramid.  Those two launches no longer exist (the march writes the next warped image itself); kept only as the clearly
+    named secondary figure frac_r02_accounting so that the rounds compare -- and as the truth when OFX_ITER_FUSED=0 brings them back"""
     px = level_px(w, h, levels, rows)
     return (LK_BYTES_PER_PX + (iters - 1) * (WARP_BYTES_PER_PX + LK_ACC_BYTES_PER_PX)) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
 
 
-def iters_pair_bytes_fused(w, h, levels, iters, rows=None):
-    """the same pair counted for the launches as they run since round 3 (SURVEY 8d's rule: every array once per stage): every
-    launch but the last also writes the warped image of the iteration after it (csrc/lk_body_warp.h) -- iteration 1: 10 B/px +
-    warp source 1 read + warped 1 written; iterations 2 .. n-1: prev 1 + warped 1 + warp source 1 + flow 8 read, flow 8 + warped' 1
-    written = 20 B/px; the last iteration writes no image (18 B/px); there is no warp pass"""
+def launch_bytes(w, h, levels, iters, rows=None, fused=True):
+    """algorithmic bytes PER PAIR of every kind of launch AS IT RUNS (SURVEY 8d's rule: every array once per stage, at its stored
+    size), keyed like engine.Session.TIME_KINDS.  With iterations (fused: the march of iteration j also writes the warped image
+    iteration j + 1 reads, csrc/lk_body_warp.h): iteration 1 = 10 B/px + warp source 1 read + warped 1 written; a middle iteration
+    = prev 1 + warped 1 + warp source 1 + flow 8 read, flow 8 + warped' 1 written = 20; the last one writes no image = 18; the
+    shift launch in front (the globally shifted next image is the warp's source) 1 + 1 on every level but the top."""
     px = level_px(w, h, levels, rows)
-    extra = 0 if iters <= 1 else 2 + (iters - 2) * (LK_ACC_BYTES_PER_PX + 2) + LK_ACC_BYTES_PER_PX
-    return (LK_BYTES_PER_PX + extra) * sum(px) + PYR_BYTES_PER_DST_PX * sum(px[1:])
+    S, pyr = sum(px), PYR_BYTES_PER_DST_PX * sum(px[1:])
+    first = LK_BYTES_PER_PX + (2 if iters > 1 and fused else 0)
+    return {"stream": first * S + pyr, "lk": first * S, "pyramid": pyr, "corner": 0, "shift": 2 * sum(px[:-1]),
+            "lk_acc_warp": (LK_ACC_BYTES_PER_PX + 2) * S, "lk_acc": LK_ACC_BYTES_PER_PX * S, "warp": WARP_BYTES_PER_PX * S}
 
 
-ITERS_ACCOUNTING = ("frac counts 28 B/px per extra iteration (a warp pass + an accumulating pass: the accounting of rounds 1-2, kept so that "
-                    "the figures stay comparable); frac_as_launched counts the launches as they run now -- 20 B/px per iteration that also "
-                    "writes the next one's warped image, 18 for the last, no warp pass")
+def dominant_block(kinds, pairs_per_launch, w, h, levels, iters, rows=None):
+    """the launch kind a pair spends most of its time in, with ITS OWN roofline (bytes of one launch / its average duration)"""
+    fused = not kinds.get("warp", (0, 0, 0))[2]
+    lb = launch_bytes(w, h, levels, iters, rows, fused)
+    k = max((k for k, v in kinds.items() if v[2]), key=lambda k: kinds[k][0] * kinds[k][2])
+    names = {"stream": "stream_kernel", "lk": "lk_level_kernel / lk_iter_kernel<.., 3> (iteration 1)", "lk_acc": "lk_iter_kernel<.., ITER = 1> (last iteration)",
+             "lk_acc_warp": "lk_iter_kernel<.., ITER = 2> (a middle iteration: flow += LK(prev, warped), and the next warped image)",
+             "warp": "warp_u8_kernel", "shift": "shift_1ch_kernel", "pyramid": "pyramid_fused_kernel", "corner": "corner_kernel"}
+    return roofline_block(pairs_per_launch * lb[k], kinds[k][0], kernel=names.get(k, k), kind=k, pairs_per_launch=pairs_per_launch,
+                          algorithmic_bytes_per_launch=pairs_per_launch * lb[k], avg_launch_us=round(kinds[k][0], 2),
+                          min_launch_us=round(kinds[k][1], 2), launches_timed=kinds[k][2],
+                          share_of_pair_time=round(kinds[k][0] * kinds[k][2] / sum(v[0] * v[2] for v in kinds.values() if v[2]), 3))
+
+
+def pair_roofline(kinds, launches_of_pairs, w, h, levels, iters, rows=None, pairs_per_launch=1):
+    """roofline of a whole pair from the event-timed launches of a pass: kinds = {kind: (avg_us, min_us, count)} over
+    `launches_of_pairs` pairs, every launch carrying `pairs_per_launch` of them.  Every byte count is that of the launches as they ran (launch_bytes); frac_r02_accounting is the
+    old 28-B/px-per-extra-iteration figure."""
+    fused = not kinds.get("warp", (0, 0, 0))[2]
+    lb = launch_bytes(w, h, levels, iters, rows, fused)
+    us_pair = sum(v[0] * v[2] for v in kinds.values() if v[2]) / launches_of_pairs
+    nbytes = sum(lb[k] * v[2] * pairs_per_launch for k, v in kinds.items() if v[2]) / launches_of_pairs
+    detail = {}
+    for k, v in kinds.items():
+        if v[2]:
+            detail[k] = {"avg_us": round(v[0], 2), "launches_per_pair": round(v[2] / launches_of_pairs, 4), "pairs_per_launch": pairs_per_launch,
+                         "algorithmic_bytes_per_pair_and_launch": lb[k]}
+    out = roofline_block(nbytes, us_pair, algorithmic_bytes_per_pair=int(nbytes), kernel_us_per_pair=round(us_pair, 2), launches=detail,
+                         accounting="bytes of the launches as they run (bench.py launch_bytes)")
+    if iters > 1:
+        out["frac_r02_accounting"] = round(iters_pair_bytes_r02(w, h, levels, iters, rows) / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        out["frac_r02_accounting_note"] = ("28 B/px per extra iteration (a warp pass + an accumulating pass): the launches of rounds 1-2, "
+                                           "which no longer run; for comparison across rounds only")
+    return out
 
 
 def roofline_block(nbytes, us, **more):
@@ -227,8 +268,9 @@ def parse_args():
                          "the solve in its <= 1 ulp formulation (OFX_MODE_LK_FLOAT_FAST); compat_cpu: cpu::calc_optical_flow bug for bug")
     ap.add_argument("--path", default="stream", choices=["stream", "staged", "plain"],
                     help="single-GPU execution path: stream pipeline (default), two-stream staged pairs, or the plain sequence")
-    ap.add_argument("--iters", type=int, default=1,
-                    help="refinement iterations per level (extension; 1 = the reference's algorithm). iters > 1 runs the plain path")
+    ap.add_argument("--iters", type=int, default=0,
+                    help="refinement iterations per level: 0 (default) = what BASELINE.json's config says (4K / 1080p: 5, 8K: 10, vga: 3: the "
+                         "lk_iter extension); 1 = the reference's own algorithm (no iteration exists there)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the additional legs reported under extra (profiling runs: only the timed configuration's launches)")
@@ -244,13 +286,39 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, choices=list(range(0, 17)),
                     help="stream path: frames per launch (ofx_params.stream_batch) = frames per step.  0 = "
                          "engine.suggest_stream_batch: by the working set of the pipeline (4K: 8 on one GPU, 8 per rank of a sharded pair)")
-    ap.add_argument("--shard-halo", default="recompute", choices=["recompute", "exchange"],
-                    help="N > 1: halo rows of every level rebuilt from a wider level-0 halo (default) or exchanged with the neighbouring "
-                         "ranks per level (RCCL send/recv; pair-at-a-time, implies --shard-corner broadcast)")
+    ap.add_argument("--shard-halo", default="stream_exchange", choices=["stream_exchange", "recompute", "exchange"],
+                    help="N > 1: stream_exchange (default) = every rank is handed ONLY ITS OWN ROWS of a frame; the level-0 halo rows and the "
+                         "top-left patch cross ranks in one batched RCCL send/recv group per tick, the halos of the coarser levels are "
+                         "recomputed, the stream pipeline runs on the assembled buffers; recompute = every rank is handed the whole frame "
+                         "(replicated input: no byte crosses xGMI); exchange = north_star's literal per-level halo exchange, pair at a "
+                         "time (implies --shard-corner broadcast)")
     ap.add_argument("--shard-corner", default="local", choices=["local", "broadcast"],
                     help="N > 1: where a rank gets the shift vectors from (local = its own top-left patch, no collective; "
                          "broadcast = rank 0's corner kernel + one RCCL broadcast per pair)")
-    return ap.parse_args()
+    ap.add_argument("--ring", type=int, default=0,
+                    help="stream paths: distinct frame buffers of the input ring; 0 = as many as the pipeline needs and at least enough "
+                         "that the ring exceeds the 256 MiB Infinity Cache (a frame never comes round again while still cached)")
+    args = ap.parse_args()
+    if args.iters <= 0:
+        args.iters = BASELINE_ITERS[args.workload]
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start it as a CHILD process -- this process has not imported torch
+    and made no HIP call, and never will (a process that has touched the GPU must not be replaced or forked into ranks) -- and
+    return its exit code.  Rank 0's JSON line reaches stdout through the inherited descriptor."""
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (dmabuf IPC: what RCCL needs on this host driver)
+    print(f"bench.py: --gpus {args.gpus} without WORLD_SIZE: starting {' '.join(cmd[1:8])} ... as a child process", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def plan_stream(args):
@@ -266,7 +334,10 @@ def plan_stream(args):
     bw, bh, bl, bwin = WORKLOADS[args.workload]
     if args.batch == 0:
         n_ranks = max(args.gpus, int(os.environ.get("WORLD_SIZE", "1")))
-        args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks) if n_ranks > 1 else None, args.borrow, args.two_stage)
+        if args.iters > 1 and n_ranks == 1:
+            args.batch = iters_batch(bw, bh, bl)
+        else:
+            args.batch = suggest_stream_batch(bw, bh, bl, ShardPlan(bw, bh, bl, bwin, 0, n_ranks, iters=args.iters) if n_ranks > 1 else None, args.borrow, args.two_stage)
     while args.batch > 1 and args.batch * bl > MAX_LK_ITEMS:
         args.batch -= 1
     # (in a short launch the two-stage pipeline's corner blocks -- they build their own patch pyramids -- are what
@@ -275,11 +346,31 @@ def plan_stream(args):
         args.two_stage = False   # (8K, two frames per launch: the patch of six levels and a 15x15 window is 544 pixels wide -- 129k vs 217k Mpix/s)
 
 
+def iters_batch(w, h, levels):
+    """pairs per launch for a stream with refinement iterations (measured: 16 at 1080p, 8 at 4K -- 28.2k vs 27.4k Mpix/s at 4 --, 2 at 8K)"""
+    if 16 * levels <= MAX_LK_ITEMS and w * h <= 1920 * 1080:
+        return 16
+    return 8 if 8 * levels <= MAX_LK_ITEMS and w * h <= 3840 * 2160 else 2
+
+
 def ring_size(batch, two_stage):
     """distinct frame buffers of the ring the stream paths read: ofx_params.borrow_frames keeps frame f's buffer in use until the
     launch of submit f + d * batch (d = 2 ticks in two stages, 3 in three)"""
     depth = 2 if two_stage else 3
     return (depth * max(batch, 4) + 4 + 3) // 4 * 4
+
+
+INFINITY_CACHE_BYTES = 256 << 20   # MI355X_MICROARCH.md: 256 MiB of MALL in front of HBM
+
+
+def cold_ring_size(batch, two_stage, frame_bytes):
+    """ring_size, raised until the ring alone exceeds the Infinity Cache by a quarter: the frames' bytes never change in a bench, so
+    a short ring would be served from that cache when a buffer comes round again -- not what a capture / decoder pipeline, which
+    writes every buffer before every use, would see"""
+    n = ring_size(batch, two_stage)
+    while n * frame_bytes < INFINITY_CACHE_BYTES * 5 // 4:
+        n += 4
+    return n
 
 
 def make_ring(src, n):
@@ -310,6 +401,17 @@ class StreamFeed:
         self.submit(self.groups[(self.frames_in // self.batch - 1) % len(self.groups)])
 
 
+class OwnRowsFeed:
+    """N > 1, --shard-halo stream_exchange: a tick = one stacked tensor [B, own rows, width] of this rank's rows of B frames"""
+
+    def __init__(self, submit, groups, batch):
+        self.submit, self.groups, self.batch, self.ticks = submit, groups, batch, 0
+
+    def tick(self, _i=None):
+        self.submit(self.groups[self.ticks % len(self.groups)])
+        self.ticks += 1
+
+
 # ---- the run ---------------------------------------------------------------------------------------------------------------
 
 class Run:
@@ -325,7 +427,8 @@ class Run:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        assert self.world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch with torch.distributed.run"
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
         torch.cuda.set_device(self.local_rank)
         # Everything is enqueued on one explicit (non-null) HIP stream: the legacy null stream serialises against every other
         # stream of the process and costs several microseconds more per launch.
@@ -340,10 +443,12 @@ class Run:
         self.nframes = 4
         self.frames = self.host_frames(self.w, self.h, args.frames)
         self.d_frames = [torch.from_numpy(f).cuda() for f in self.frames]
-        self.ring_n = int(os.environ.get("OFX_BENCH_RING", "0")) or ring_size(args.batch, args.two_stage)  # (experiments: other ring sizes)
         # The stream paths take their frames from a ring of DISTINCT device buffers, as a capture / decoder surface pool would
-        # hand them over: long enough for ofx_params.borrow_frames, and large enough that a frame is not still sitting in the
-        # 256 MB Infinity Cache when it comes round again merely because the ring is short.  Contents repeat every four buffers.
+        # hand them over: long enough for ofx_params.borrow_frames, and so long that the ring alone exceeds the 256 MiB Infinity
+        # Cache -- the buffers' bytes never change here, and a short ring would be served from that cache when a buffer comes
+        # round again (the 20-buffer ring of rounds 2-3 was; that figure is now extra.reference_defined_iters1.warm_ring).
+        # Contents repeat every four buffers.
+        self.ring_n = args.ring or int(os.environ.get("OFX_BENCH_RING", "0")) or cold_ring_size(args.batch, args.two_stage, self.w * self.h)
         self.d_ring = make_ring(self.d_frames, self.ring_n)
 
     def host_frames(self, w, h, kind="texture"):
@@ -434,7 +539,21 @@ class Run:
                                                     stream_batch=args.batch, halo_mode=args.shard_halo, iters=args.iters,
                                                     borrow_frames=args.borrow and args.shard_corner == "local" and args.shard_halo != "exchange")
         self.sess = driver.session
-        if args.shard_corner == "local":
+        if args.shard_halo == "stream_exchange":
+            # what a rank is handed: ITS OWN ROWS of every frame, nothing else (one stacked tensor per tick, as a sharded decoder or
+            # a row-partitioned capture would deliver them); every tick, the level-0 halo rows and the top-left patch cross ranks
+            # in one batched RCCL group (parallel.ShardedFlow.assemble_frames), then the tick's launch runs on the assembled buffers
+            o0, o1 = driver.plan.own[0]
+            B, n = args.batch, self.ring_n
+            own = [f[o0:o1].contiguous() for f in self.d_ring]
+            self.own_groups = [self.torch.stack([own[(j * B + k) % n] for k in range(B)]) for j in range(math.lcm(n, B) // B)]
+            del own
+            driver.stream_begin()
+            self.feed = OwnRowsFeed(driver.stream_submit_own_rows, self.own_groups, B)
+            self.step = self.feed.tick
+            for i in range(3):   # (fill the pipeline)
+                self.step(i)
+        elif args.shard_corner == "local":
             driver.stream_begin()
             self.feed = StreamFeed(driver.stream_submit_frames, self.d_ring, args.batch)
             self.step = self.feed.tick
@@ -507,9 +626,14 @@ class Run:
                 pass
             (sess.stream_begin if driver is None else driver.stream_begin)()
             nf = 4 * args.batch
-            submit = sess.stream_submit if driver is None else driver.stream_submit
-            for i in range(nf):
-                submit(self.d_ring[i % self.ring_n])
+            if isinstance(self.feed, OwnRowsFeed):   # through the same door as the timed ticks: own rows only, one exchange per tick
+                o0, o1 = driver.plan.own[0]
+                for t in range(nf // args.batch):
+                    driver.stream_submit_own_rows(torch.stack([self.d_ring[(t * args.batch + k) % self.ring_n][o0:o1] for k in range(args.batch)]))
+            else:
+                submit = sess.stream_submit if driver is None else driver.stream_submit
+                for i in range(nf):
+                    submit(self.d_ring[i % self.ring_n])
             while drain() != -2:
                 pass
             for p in sorted({nf - 1, nf - args.batch}):
@@ -585,12 +709,8 @@ class Run:
             else:
                 # refinement iterations: the roofline is that of the whole pair -- every launch event-timed and tagged
                 kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
-                us_pair = sum(v[0] * v[2] for v in kk.values() if v[2]) / (ticks * batch)
-                nbytes, nfused = iters_pair_bytes(w2, h2, l2, iters), iters_pair_bytes_fused(w2, h2, l2, iters)
-                res["roofline"] = roofline_block(nbytes, us_pair, algorithmic_bytes_per_pair=nbytes, kernel_us_per_pair=round(us_pair, 2),
-                                                 frac_as_launched=round(nfused / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                 algorithmic_bytes_per_pair_as_launched=nfused, accounting=ITERS_ACCOUNTING,
-                                                 launches={k: {"avg_us": round(v[0], 2), "per_tick": v[2] // ticks} for k, v in kk.items() if v[2]})
+                res["roofline"] = pair_roofline(kk, ticks * batch, w2, h2, l2, iters, pairs_per_launch=batch)
+                res["roofline"]["dominant_kernel"] = dominant_block(kk, batch, w2, h2, l2, iters)
             s2.timing(0)
         s2.close()
         return res
@@ -598,7 +718,7 @@ class Run:
     def device_ring(self, wl, batch, two_stage, kind="texture"):
         w2, h2 = wl[:2]
         src = [self.torch.from_numpy(f).cuda() for f in self.host_frames(w2, h2, kind)]
-        return make_ring(src, ring_size(batch, two_stage))
+        return make_ring(src, cold_ring_size(batch, two_stage, w2 * h2))   # (longer than the Infinity Cache: rows come from HBM)
 
     # ---- extra legs (single GPU), one function each ------------------------------------------------------------------------
     def leg_iters_pair_at_a_time(self, wl, it, d_frames, steps):
@@ -628,25 +748,11 @@ class Run:
         kk = {k: s2.timing_read_kind(k) for k in engine.Session.TIME_KINDS}
         s2.timing(0)
         s2.close()
-        px = level_px(w, h, levels)
-        per_kind_bytes = {"lk": LK_BYTES_PER_PX * sum(px), "lk_acc": LK_ACC_BYTES_PER_PX * sum(px), "warp": WARP_BYTES_PER_PX * sum(px),
-                          "shift": 2 * sum(px[:-1]), "pyramid": PYR_BYTES_PER_DST_PX * sum(px[1:])}
-        launches = {}
-        for k, (avg, mn, cnt) in kk.items():
-            if cnt:
-                launches[k] = {"avg_us": round(avg, 2), "per_pair": cnt // n2}
-                if k in per_kind_bytes:
-                    launches[k]["algorithmic_bytes"] = per_kind_bytes[k]
-                    launches[k]["frac"] = round(per_kind_bytes[k] / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-        pair_alg = iters_pair_bytes(w, h, levels, it)
-        kernel_us = sum(v[0] * (v[2] // n2) for v in kk.values() if v[2])
+        roof = pair_roofline(kk, n2, w, h, levels, it)
+        roof["timed_in"] = "second pass, hipEventRecord around every launch of the pair"
         return {"workload": f"{w}x{h}, {levels} levels, {window}x{window}, iters={it} (extension lk_iter: bilinear-warp refinement), pair at a time",
                 "value": round(w * h / (ms2 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms2, 5), "frames_per_s": round(1e3 / ms2, 1),
-                "pairs_timed": n2,
-                "roofline": roofline_block(pair_alg, kernel_us, algorithmic_bytes_per_pair=pair_alg, kernel_us_per_pair=round(kernel_us, 2),
-                                           frac_as_launched=round(iters_pair_bytes_fused(w, h, levels, it) / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                           algorithmic_bytes_per_pair_as_launched=iters_pair_bytes_fused(w, h, levels, it), accounting=ITERS_ACCOUNTING,
-                                           launches=launches, timed_in="second pass, hipEventRecord around every launch of the pair")}
+                "pairs_timed": n2, "roofline": roof}
 
     def leg_baseline_config(self, name, steps):
         """BASELINE config `name` as it is written: its iterations (streamed: one warp + one accumulating LK launch per iteration
@@ -661,15 +767,14 @@ class Run:
             b1 = self.engine.suggest_stream_batch(w2, h2, l2, None, True, False)
         ring1 = self.device_ring(wl, b1, two1)
         r1 = self.stream_leg(wl, self.args.mode, b1, True, ring1, steps, two_stage=two1)
-        r1["workload"] = f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters=1, stream path, {b1} frames per launch"
+        r1["workload"] = (f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters=1, stream path, {b1} frames per launch, ring of {len(ring1)} "
+                          f"buffers ({len(ring1) * w2 * h2 / 1e6:.0f} MB)")
         out["iters1"] = r1
-        # (pairs per launch for the iterations: 8 where the items fit -- 4K: 28.2k vs 27.4k Mpix/s at 4 since the accumulating
-        # launches write the next iteration's warped images; 8K: 2)
-        bi = 16 if 16 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 1920 * 1080 else (8 if 8 * l2 <= MAX_LK_ITEMS and w2 * h2 <= 3840 * 2160 else 2)
+        bi = iters_batch(w2, h2, l2)
         ringi = ring1 if len(ring1) >= 3 * bi + 1 else self.device_ring(wl, bi, False)
         ri = self.stream_leg(wl, self.args.mode, bi, True, ringi, steps, two_stage=False, iters=it, min_launches=12 if w2 * h2 <= 3840 * 2160 else 6)
-        ri["workload"] = (f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters={it} (extension lk_iter), streamed: {bi} pairs per "
-                          "launch, frames read in place")
+        ri["workload"] = (f"{w2}x{h2} pair, {l2}-level pyramid, {win2}x{win2} window, iters={it}: BASELINE.json config as written (extension lk_iter), streamed: "
+                          f"{bi} pairs per launch, frames read in place from a ring of {len(ringi)} buffers ({len(ringi) * w2 * h2 / 1e6:.0f} MB)")
         out[f"iters{it}"] = ri
         del ring1, ringi
         return out
@@ -772,70 +877,159 @@ class Run:
             del img, gray, filt
         return fe
 
+    def leg_fresh_frames(self, wl, mode, batch, two_stage, steps):
+        """VERDICT r03 'missing' 5: a capture / decoder pipeline WRITES every buffer before every use; a bench whose ring never changes
+        reads buffers that may still sit in the Infinity Cache (short ring) or certainly do not (long ring) -- neither is that.  Here
+        a producer rewrites each buffer of a tick (a device-to-device copy from a pool of source frames, on the same stream, right
+        before the tick that takes it: case (a) of the lifetime rule in include/ofx.h) -- the frame's bytes are as fresh as a
+        decoder's output, and the copies are part of the timed region (they move 2 B/px on top of the pair's bytes)."""
+        torch, engine = self.torch, self.engine
+        w2, h2, l2, win2 = wl
+        src = [torch.from_numpy(f).cuda() for f in self.host_frames(w2, h2)]
+        ring = make_ring(src, ring_size(batch, two_stage))   # the SHORT ring on purpose: freshness comes from the rewrite, not from its length
+        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=True, two_stage=two_stage)
+        s2.stream_begin()
+        n = len(ring)
+        groups = [engine.FrameGroup([ring[(j * batch + k) % n] for k in range(batch)]) for j in range(math.lcm(n, batch) // batch)]
+        state = {"f": 0}
+
+        def tick():
+            j = state["f"] // batch
+            for k in range(batch):
+                ring[(state["f"] + k) % n].copy_(src[(state["f"] + k) % len(src)])   # the "decoder": writes the buffer, then hands it over
+            s2.stream_submit_frames(groups[j % len(groups)])
+            state["f"] += batch
+        t_end = time.perf_counter() + 0.15
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                tick()
+            torch.cuda.synchronize()
+        ticks = max(50, steps)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(ticks):
+            tick()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / (ticks * batch) * 1e3
+        s2.timing(ticks * 3)
+        for _ in range(ticks):
+            tick()
+        torch.cuda.synchronize()
+        avg, mn, cnt = s2.timing_read()
+        s2.timing(0)
+        s2.close()
+        nb = batch * pair_bytes(w2, h2, l2)
+        return {"workload": (f"reference-defined pipeline (iters=1), {batch} frames per launch, ring of {n} buffers, EVERY buffer rewritten by a device copy on "
+                             "the same stream right before the tick that takes it (a decoder's output is always fresh); the copies are inside the timed region"),
+                "value": round(w2 * h2 / (ms * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms, 5), "pairs_timed": ticks * batch,
+                "roofline": roofline_block(nb, avg, kernel="stream_kernel", algorithmic_bytes_per_launch=nb, avg_launch_us=round(avg, 2), launches_timed=cnt)}
+
+    def leg_primitives(self):
+        """the stand-alone window-sum entry points behind gpu::srm_1ch / gpu::srm_1ch_float (OptFlowGpu.cu:1463-1502, 1549-1588), device
+        resident, 4K planes, 9x9: SURVEY 8d's 5-plane accounting -- (2 s + 4) B/px per call, s = 1 for the u8 form (6), 4 for the
+        float form (12); five calls per level = 30 / 60 B/px"""
+        from cuda_optical_flow_2_amd import lib as _l
+
+        torch = self.torch
+        L_ = _l.load()
+        out = {}
+        wa, ha = 3840, 2160
+        a8 = torch.from_numpy(self.host_frames(wa, ha)[0]).cuda()
+        b8 = torch.from_numpy(self.host_frames(wa, ha)[1]).cuda()
+        d32 = torch.empty((ha, wa), dtype=torch.int32, device="cuda")
+        af, bf = (a8.float() - 128.0).contiguous(), (b8.float() - 100.0).contiguous()
+        df = torch.empty((ha, wa), dtype=torch.float32, device="cuda")
+        st_ = torch.cuda.current_stream().cuda_stream
+
+        def timed(fn, reps):
+            fn(); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps * 1e3
+        for win in (9, 19):
+            t_u = timed(lambda: _l.check(L_.ofx_srm_u8(a8.data_ptr(), b8.data_ptr(), wa, ha, win, win, d32.data_ptr(), st_), "srm_u8"), 10)
+            t_f = timed(lambda: _l.check(L_.ofx_srm_f32(af.data_ptr(), bf.data_ptr(), wa, ha, win, win, df.data_ptr(), st_), "srm_f32"), 10)
+            out[f"srm_1ch_4k_{win}x{win}"] = dict(roofline_block(6 * wa * ha, t_u, kernel="ofx_srm_u8 (gpu::srm_1ch / cpu::srm_1ch)", avg_launch_us=round(t_u, 1),
+                                                                 algorithmic_bytes_per_launch=6 * wa * ha), five_calls_us=round(5 * t_u, 1))
+            out[f"srm_1ch_float_4k_{win}x{win}"] = dict(roofline_block(12 * wa * ha, t_f, kernel="ofx_srm_f32 (gpu::srm_1ch_float)", avg_launch_us=round(t_f, 1),
+                                                                       algorithmic_bytes_per_launch=12 * wa * ha), five_calls_us=round(5 * t_f, 1))
+        return out
+
     def extras_single_gpu(self):
         args, engine = self.args, self.engine
         w, h, levels, window = self.w, self.h, self.levels, self.window
         wl = (w, h, levels, window)
         extra = {}
-        if not (args.iters <= 1 and args.mode == "lk_float" and args.workload in BASELINE_ITERS):
+        if not (args.mode == "lk_float" and args.workload in BASELINE_ITERS and args.path == "stream"):
             return extra
-        # BASELINE.json's configs carry "N iters"; the reference has no iterations, so they run as the
-        # lk_iter extension here, next to the reference-defined line above (same process, same frames)
         it = BASELINE_ITERS[args.workload]
-        lit = self.leg_iters_pair_at_a_time(wl, it, self.d_frames, args.steps)
-        b9 = 8 if 8 * levels <= MAX_LK_ITEMS and w * h <= 3840 * 2160 else (4 if 4 * levels <= MAX_LK_ITEMS else 2)   # (4K: 8 pairs per launch +2.6 % over 4)
-        streamed = self.stream_leg(wl, args.mode, b9, args.borrow, self.d_ring if len(self.d_ring) >= 3 * b9 + 1 else make_ring(self.d_frames, ring_size(b9, False)),
-                                   args.steps, two_stage=False, iters=it, min_launches=12)
-        streamed["workload"] = f"as above through the stream pipeline, {b9} pairs per launch, frames " + ("read in place" if args.borrow else "copied")
-        lit["streamed"] = streamed
-        extra["baseline_config_with_iters"] = lit
-        if args.path == "stream" and args.borrow:
-            # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
-            # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
-            b3 = engine.suggest_stream_batch(w, h, levels, None, False)
-            r3 = self.stream_leg(wl, args.mode, b3, False, self.d_ring[:16] if len(self.d_ring) > 16 else self.d_ring, args.steps)
-            r3["workload"] = f"as value, but the session copies level 0 of every frame ({b3} frames per launch)"
-            extra["stream_with_copied_frames"] = r3
-            # cache-cold inputs: the ring is long enough that neither the frames nor the session's image sets survive in the
-            # 256 MB Infinity Cache between their uses, i.e. every image row the level kernel reads comes from HBM -- what a
-            # pipeline fed from a large surface pool sees
-            cold_n = max(32, 2 * self.ring_n)
-            if w * h * cold_n < 40e9:
-                cold_ring = make_ring(self.d_frames, cold_n)
-                r6 = self.stream_leg(wl, args.mode, args.batch, True, cold_ring, args.steps)
-                r6["workload"] = (f"as value, frames read in place from a ring of {cold_n} distinct buffers ({w * h * cold_n / 1e6:.0f} MB: nothing "
-                                  "survives in the Infinity Cache between uses)")
-                extra["cold_inputs"] = r6
-                del cold_ring
-        if args.path == "stream":
-            if args.frames == "texture":
-                # SURVEY 8d's worst case for value ranges next to the smooth texture: uniform-random u8 frames (seed 1).  Every window sum
-                # of such a pair is far beyond 2^24, every derivative near its range: no data-dependent shortcut can flatter this leg.
-                rr = self.device_ring(wl, args.batch, args.two_stage, "random")
-                r10 = self.stream_leg(wl, args.mode, args.batch, args.borrow, rr, args.steps)
-                r10["workload"] = "as value, on uniform-random u8 frames (synth.random_pair, seeds 1 and 2) instead of the smooth texture"
-                extra["random_pair"] = r10
-                del rr
-            # the same pipeline with the solve in its <= 1 ulp(float) formulation (OFX_MODE_LK_FLOAT_FAST: SURVEY 8c's stated
-            # tolerance for the solve, identical NaN / Inf positions; window sums, shift and pyramid stay bit-exact)
-            r8 = self.stream_leg(wl, "lk_float_fast", args.batch, args.borrow, self.d_ring, args.steps)
-            r8["workload"] = "as value, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
-            extra["fast_solve"] = r8
-            # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
-            bc = engine.suggest_stream_batch(w, h, levels, None, args.borrow, args.two_stage)
-            r7 = self.stream_leg(wl, "compat_cpu", bc, args.borrow, self.d_ring if bc == args.batch else make_ring(self.d_frames, ring_size(bc, args.two_stage)), args.steps)
-            r7["workload"] = f"as value, mode compat_cpu (OptFlowCPU.cpp:312-399 bug for bug; stream path, {bc} frames per launch)"
-            extra["compat_cpu"] = r7
-            extra["plain_path"] = self.leg_plain_path(args.steps)
-        if args.path == "stream" and args.workload == "4k":
+        # ---- the reference-defined pipeline (iters = 1: the only value the reference has; SURVEY 8d's additional run), as rounds 1-3
+        # timed it at top level: two stages, eight 4K frames per launch, frames read in place
+        b1 = engine.suggest_stream_batch(w, h, levels, None, True, True)
+        two1 = b1 >= 5 and b1 * w * h >= OFX_TWO_STAGE_MIN_PIXELS
+        if not two1:
+            b1 = engine.suggest_stream_batch(w, h, levels, None, True, False)
+        cold_n = cold_ring_size(b1, two1, w * h)
+        cold_ring = self.d_ring if len(self.d_ring) >= cold_n else make_ring(self.d_frames, cold_n)
+        r1 = self.stream_leg(wl, args.mode, b1, True, cold_ring, args.steps, two_stage=two1)
+        r1["workload"] = (f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters=1 (the reference's own algorithm), stream path, {b1} frames "
+                          f"per launch, {'two' if two1 else 'three'} stages, frames read in place from a ring of {len(cold_ring)} distinct buffers "
+                          f"({len(cold_ring) * w * h / 1e6:.0f} MB > the 256 MiB Infinity Cache: every frame row comes from HBM)")
+        warm_ring = make_ring(self.d_frames, ring_size(b1, two1))
+        rw = self.stream_leg(wl, args.mode, b1, True, warm_ring, args.steps, two_stage=two1)
+        rw["workload"] = (f"the same from the ring of {len(warm_ring)} buffers ({len(warm_ring) * w * h / 1e6:.0f} MB) rounds 2-3 timed at top level: its never-rewritten "
+                          "frames are re-read from the Infinity Cache (VERDICT r03 weak 2) -- an upper bound, not the defensible figure")
+        r1["warm_ring"] = rw
+        del warm_ring
+        extra["reference_defined_iters1"] = r1
+        extra["fresh_frames"] = self.leg_fresh_frames(wl, args.mode, b1, two1, args.steps)
+        if args.iters == 1:
+            # (--iters 1 at top level: the config as written goes here instead)
+            bi = iters_batch(w, h, levels)
+            ri = self.stream_leg(wl, args.mode, bi, True, cold_ring if len(cold_ring) >= 3 * bi + 1 else make_ring(self.d_frames, cold_ring_size(bi, False, w * h)),
+                                 args.steps, two_stage=False, iters=it, min_launches=12)
+            ri["workload"] = f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={it}: BASELINE.json config as written, streamed, {bi} pairs per launch"
+            extra["baseline_config_as_written"] = ri
+        extra["baseline_config_pair_at_a_time"] = self.leg_iters_pair_at_a_time(wl, it, self.d_frames, args.steps)
+        # the same stream path with the session's own copy of level 0 of every frame (ofx_params.borrow_frames = 0: the
+        # caller may reuse a frame buffer as soon as the launch that took it has run), at the frames per launch that suit it
+        b3 = engine.suggest_stream_batch(w, h, levels, None, False)
+        r3 = self.stream_leg(wl, args.mode, b3, False, cold_ring[:16], args.steps, two_stage=False)
+        r3["workload"] = f"reference-defined pipeline (iters=1), the session copies level 0 of every frame ({b3} frames per launch)"
+        extra["stream_with_copied_frames"] = r3
+        if args.frames == "texture":
+            # SURVEY 8d's worst case for value ranges next to the smooth texture: uniform-random u8 frames (seed 1).  Every window sum
+            # of such a pair is far beyond 2^24, every derivative near its range: no data-dependent shortcut can flatter this leg.
+            src = [self.torch.from_numpy(f).cuda() for f in self.host_frames(w, h, "random")]
+            rr = make_ring(src, cold_n)
+            r10 = self.stream_leg(wl, args.mode, b1, True, rr, args.steps, two_stage=two1)
+            r10["workload"] = "reference-defined pipeline (iters=1) as reference_defined_iters1, on uniform-random u8 frames (synth.random_pair, seeds 1 and 2)"
+            extra["random_pair"] = r10
+            del rr, src
+        # the same pipeline with the solve in its <= 1 ulp(float) formulation (OFX_MODE_LK_FLOAT_FAST: SURVEY 8c's stated
+        # tolerance for the solve, identical NaN / Inf positions; window sums, shift and pyramid stay bit-exact)
+        r8 = self.stream_leg(wl, "lk_float_fast", b1, True, cold_ring, args.steps, two_stage=two1)
+        r8["workload"] = "as reference_defined_iters1, mode lk_float_fast (solve within 1 float ulp of the replayed reference solve instead of bit-identical)"
+        extra["fast_solve"] = r8
+        # the mode that IS pinned against the reference's own execution (cpu::calc_optical_flow bug for bug)
+        r7 = self.stream_leg(wl, "compat_cpu", b1, True, cold_ring, args.steps, two_stage=two1)
+        r7["workload"] = f"as reference_defined_iters1, mode compat_cpu (OptFlowCPU.cpp:312-399 bug for bug; stream path, {b1} frames per launch)"
+        extra["compat_cpu"] = r7
+        del cold_ring
+        extra["plain_path"] = self.leg_plain_path(args.steps)
+        if args.workload == "4k":
             # the metric names 1080p pairs next to 4K ones, and BASELINE.json's configs carry their own iterations: the 1080p
             # and the 8K configuration as written and with iters = 1 (short legs: an 8K pair with ten iterations is milliseconds)
             c2 = self.leg_baseline_config("1080p", args.steps)
-            extra["workload_1080p"] = c2["iters1"]
             extra["workload_1080p_iters5"] = c2["iters5"]
+            extra["workload_1080p_iters1"] = c2["iters1"]
             c5 = self.leg_baseline_config("8k", min(args.steps, 40))
-            extra["workload_8k"] = c5["iters1"]
             extra["workload_8k_iters10"] = c5["iters10"]
+            extra["workload_8k_iters1"] = c5["iters1"]
+        extra["primitives"] = self.leg_primitives()
         extra["api_compat"] = self.leg_api_compat()
         extra["frontend"] = self.leg_frontend()
         return extra
@@ -850,10 +1044,10 @@ class Run:
 
         extra = {}
         # (frames per launch as at N = 1: eight only pay when a launch carries a fraction of a pair)
-        b4 = engine.suggest_stream_batch(w, h, levels, None, args.borrow)
-        s4 = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, borrow_frames=args.borrow, stream_batch=b4)
+        b4 = iters_batch(w, h, levels) if args.iters > 1 else engine.suggest_stream_batch(w, h, levels, None, args.borrow)
+        s4 = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, borrow_frames=args.borrow, stream_batch=b4, iters=args.iters)
         s4.stream_begin()
-        r4 = make_ring(self.d_frames, ring_size(b4, False))
+        r4 = self.d_ring if len(self.d_ring) >= 3 * b4 + 1 else make_ring(self.d_frames, cold_ring_size(b4, False, w * h))
         fd4 = StreamFeed(s4.stream_submit_frames, r4, b4)
         t_ramp = time.perf_counter() + 0.1
         while time.perf_counter() < t_ramp:
@@ -870,10 +1064,34 @@ class Run:
         s4.close()
         del r4
         extra["independent_pairs_per_rank"] = {
-            "workload": f"every one of the {self.world} rank(s) runs the unsharded stream pipeline on its own frame pairs (no sharding, no "
+            "workload": f"every one of the {self.world} rank(s) runs the unsharded stream pipeline (iters={args.iters}) on its own frame pairs (no sharding, no "
                         "communication): aggregate pairs/s, weak scaling, latency per pair as on one GPU",
             "value": round(self.world * w * h / (ms4 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_step_per_rank": round(ms4, 5),
             "frames_per_rank": n4}
+        if args.shard_halo == "stream_exchange":
+            # the same sharded pipeline with REPLICATED input (every rank is handed the whole frame, as rounds 1-3 timed N > 1 at
+            # top level): no byte crosses xGMI -- what the exchange of the top-level figure costs is the difference
+            drv3 = parallel.ShardedFlow(w, h, levels, window, args.mode, self.rank, self.world, device=self.local_rank, corner="local",
+                                        stream_batch=args.batch, halo_mode="recompute", iters=args.iters, borrow_frames=args.borrow)
+            drv3.stream_begin()
+            fd3 = StreamFeed(drv3.stream_submit_frames, self.d_ring, args.batch)
+            t_ramp = time.perf_counter() + 0.1
+            while time.perf_counter() < t_ramp:
+                for i in range(8):
+                    fd3.tick()
+                torch.cuda.synchronize()
+            n3 = max(args.steps, 8)
+            self.fence()
+            t0 = time.perf_counter()
+            for i in range(n3):
+                fd3.tick()
+            self.fence()
+            ms3 = self.max_over_ranks(time.perf_counter() - t0) / (n3 * args.batch) * 1e3
+            st3 = drv3.corner_status()
+            drv3.session.close()
+            extra["replicated_input"] = {
+                "workload": f"as value, but every rank is handed the WHOLE frame (halo_mode='recompute'): no exchange, no byte over xGMI; {args.batch} frames per tick",
+                "value": round(w * h / (ms3 * 1e-3) / 1e6, 1), "unit": "Mpix/s", "ms_per_pair": round(ms3, 5), "ticks": n3, "status_word": st3}
         # north_star's literal formulation, so that a scaling run shows RCCL carrying the halos: every rank holds only its own
         # rows (+ halo) of the pair, exchanges the halo rows of every pyramid level with its neighbours (batched send/recv) and
         # receives the shift vectors by broadcast.  Pair-at-a-time, latency-bound: a short leg.
@@ -902,33 +1120,29 @@ class Run:
         return extra
 
     # ---- the line ---------------------------------------------------------------------------------------------------------------
-    def traffic(self):
-        """HBM bytes per launch of the dominant kernel from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        separate passes, tools/profile_round.sh) -- a STORED figure, not a measurement of this run: reported with its provenance,
-        and dropped when the kernel sources have changed since it was taken."""
+    def traffic(self, kname):
+        """HBM bytes per launch of kernel `kname` from profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        separate passes, tools/profile_round.sh) -- a STORED figure, not a measurement of this run: reported with its provenance
+        (flat fields, so that a driver that keeps only scalars keeps them), and withheld when the kernel sources have changed
+        since it was taken.  Returns (bytes or None, {field: value})."""
         args = self.args
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if self.driver is not None or not os.path.exists(tpath):
-            return None, None
+            return None, {}
         try:
             doc = json.load(open(tpath))
             t = doc.get(args.workload)
-            kname = "stream_kernel" if args.path == "stream" else "lk_level_kernel"
-            if args.mode != "lk_float" or args.iters > 1:
-                kname += f"_{args.mode}_iters{args.iters}"
             nbytes = t.get(kname) if isinstance(t, dict) else None
-            # (tools/pmc_run.py measures the default plan: two stages with the suggested frames per launch)
-            if args.path == "stream" and args.iters <= 1 and not (args.two_stage and args.batch == self.engine.suggest_stream_batch(self.w, self.h, self.levels, None, True, True)):
-                nbytes = None
-            src = {"file": "profiles/traffic_latest.json", "tool": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_round.sh)",
-                   "measured_at_commit": doc.get("measured_at_commit"), "kernel_source_sha16": doc.get("kernel_source_sha16"),
-                   "note": "stored figure from the profiling run named here, not a measurement of this run"}
+            src = {"traffic_source": f"stored: profiles/traffic_latest.json[{args.workload}][{kname}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                     "passes, tools/profile_round.sh), not a measurement of this run",
+                   "traffic_measured_at_commit": doc.get("measured_at_commit"), "traffic_kernel_source_sha16": doc.get("kernel_source_sha16"),
+                   "traffic_pairs_per_launch": (doc.get("pairs_per_launch") or {}).get(kname)}
             if doc.get("kernel_source_sha16") != kernel_source_hash():
-                src["stale"] = "the kernel sources have changed since the profile was taken: figure withheld"
+                src["traffic_stale"] = "the kernel sources have changed since the profile was taken: figure withheld"
                 nbytes = None
             return nbytes, src
         except Exception:
-            return None, None
+            return None, {}
 
     def line(self, check_msg, extra):
         args, driver, fps = self.args, self.driver, self.fps
@@ -936,46 +1150,56 @@ class Run:
         ms = self.dt / args.steps * 1e3
         stream_like = self.feed is not None
         own_rows = None if driver is None else driver.plan.own
-        # the timed launch is the fused LK kernel over ALL pyramid levels (one launch, ofx_lk_levels): algorithmic
-        # bytes = 10 B x the pixels of every level this rank owns
-        own_px = sum(level_px(w, h, levels, own_rows))
-        lk_bytes = LK_BYTES_PER_PX * own_px
-        if args.iters > 1:
-            # every LK launch is timed: the first writes the flow (10 B/px), the others also read it back (18 B/px)
-            lk_bytes = (LK_BYTES_PER_PX + (args.iters - 1) * LK_ACC_BYTES_PER_PX) * own_px // args.iters
-        if stream_like:
-            # the stream launch also builds the next frame's pyramid: + 5 B per destination pixel of levels 1..
-            # (a rank of a sharded run builds the rows it owns)
-            lk_bytes = pair_bytes(w, h, levels, own_rows)
         pairs_per_launch = args.batch if stream_like else 1   # a stream tick carries args.batch frames / pairs
-        lk_bytes *= pairs_per_launch
-        k_avg_us, k_min_us, k_n = self.k_avg_us, self.k_min_us, self.k_n
-        iters_pair = None
-        if args.iters > 1:
-            # refinement iterations: the roofline is that of the whole pair -- every launch of the second pass event-timed
-            # and tagged (ofx_session_timing_read_kind)
-            pair_alg = iters_pair_bytes(w, h, levels, args.iters, own_rows)
-            us_pair = sum(v[0] * v[2] for v in self.kinds.values() if v[2]) / (self.roof_steps * fps)
-            fused_alg = iters_pair_bytes_fused(w, h, levels, args.iters, own_rows)
-            iters_pair = {"algorithmic_bytes_per_pair": pair_alg, "kernel_us_per_pair": round(us_pair, 2),
-                          "frac_as_launched": round(fused_alg / (us_pair * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if driver is None else None,
-                          "algorithmic_bytes_per_pair_as_launched": fused_alg if driver is None else None, "accounting": ITERS_ACCOUNTING,
-                          "launches": {k: {"avg_us": round(v[0], 2), "count": v[2]} for k, v in self.kinds.items() if v[2]}}
-            lk_bytes, k_avg_us, k_min_us, k_n = pair_alg, us_pair, us_pair, self.roof_steps
-        achieved = lk_bytes / (k_avg_us * 1e-6) / 1e9 if k_n else 0.0
-        traffic, traffic_source = self.traffic()
+        kinds = {k: v for k, v in self.kinds.items() if v[2]}
+        # the pair as a whole (every launch of the second pass, event-timed and tagged) and the launch kind it spends most of its
+        # time in: the roofline object is the latter's -- algorithmic bytes of ONE launch as it runs / its average duration
+        whole = pair_roofline(kinds, self.roof_steps * fps, w, h, levels, args.iters, own_rows, pairs_per_launch)
+        dom = dominant_block(kinds, pairs_per_launch, w, h, levels, args.iters, own_rows)
+        tkey = {"stream": "stream_kernel", "lk": "lk_level_kernel", "lk_acc_warp": "lk_iter_kernel_iter2", "lk_acc": "lk_iter_kernel_iter1"}.get(dom["kind"], dom["kind"])
+        if args.mode != "lk_float":
+            tkey += "_" + args.mode
+        traffic, traffic_src = self.traffic(tkey)
+        if traffic is not None and traffic_src.get("traffic_pairs_per_launch") not in (None, pairs_per_launch):
+            traffic = traffic * pairs_per_launch / traffic_src["traffic_pairs_per_launch"]   # (profiled at another tick size: per pair it is the same launch)
         borrowed = args.borrow and ((driver is None and args.path == "stream") or
                                     (driver is not None and args.shard_corner == "local" and args.shard_halo != "exchange"))
         frames_what = ("SURVEY 8d's smooth texture translating by (2,1) px per frame" if args.frames == "texture"
                        else "uniform-random u8 frames (synth.random_pair, seeds 1 and 2)")
-        if stream_like:
-            stages = ((f"corner flows of the {pairs_per_launch} pair(s) those frames complete, on patch pyramids the corner blocks build | fused LK of all "
-                       f"levels of the {pairs_per_launch} pair(s) before") if args.two_stage and driver is None else
-                      (f"corner flows of the {pairs_per_launch} pair(s) before | fused LK of all levels of the {pairs_per_launch} pair(s) before those"))
-            kernel = (f"stream_kernel (one launch per {pairs_per_launch} frame(s): pyramid(s) of the newest frame(s) | {stages}; bytes per pair = "
-                      "10 B/px LK + 5 B/px pyramid)")
+        ring_mb = self.ring_n * w * h / 1e6
+        ring_what = (f"a ring of {self.ring_n} distinct device buffers = {ring_mb:.0f} MB " +
+                     ("(larger than the 256 MiB Infinity Cache: a buffer that comes round again is read from HBM)" if ring_mb * 1e6 > INFINITY_CACHE_BYTES
+                      else "(SMALLER than the 256 MiB Infinity Cache: re-used buffers are served from it)") +
+                     "; contents never rewritten -- extra.fresh_frames rewrites every buffer before its tick")
+        if driver is not None and args.shard_halo == "stream_exchange":
+            o0, o1 = driver.plan.own[0]
+            frames_cfg = (f"every rank is handed ONLY ITS OWN ROWS of a frame ({o1 - o0} of {h} on rank 0; a stacked tensor per tick out of {ring_what}); per tick the "
+                          "level-0 halo rows and the top-left patch cross ranks in one batched RCCL send/recv group, then the tick's launch reads the "
+                          "assembled buffers in place")
+        elif not stream_like:
+            frames_cfg = "four resident device buffers, " + ("read in place (ofx_params.borrow_frames)" if driver is None and args.path == "plain" and args.borrow
+                                                              and w % 64 == 0 else "level 0 copied into the session per pair")
         else:
-            kernel = "lk_level_kernel (all pyramid levels in one launch: fused derivatives + window sums + 2x2 solve)"
+            frames_cfg = ring_what + ", " + (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {(2 if args.two_stage else 3) * args.batch} further submits)"
+                                             if borrowed else "level 0 copied into the session")
+        if driver is None:
+            sharding = "none"
+        elif args.shard_halo == "stream_exchange":
+            sharding = (f"row blocks over {self.world} rank(s); input arrives sharded (own rows only), level-0 halo rows + the top-left patch exchanged once per "
+                        "tick over RCCL (one message per peer and direction), halos of the coarser levels recomputed, every rank runs the stream pipeline "
+                        "on its block and forms the shift vectors from the patch: parallel.ShardedFlow halo_mode='stream_exchange' (DESIGN.md section 5)")
+        elif args.shard_halo == "exchange":
+            sharding = (f"row blocks over {self.world} rank(s), halo rows of every level exchanged with the neighbouring ranks (RCCL send/recv per level), rank 0's "
+                        "corner kernel + one RCCL broadcast of the shift vectors per pair; pair at a time")
+        else:
+            sharding = (f"row blocks over {self.world} rank(s), REPLICATED input (every rank is handed the whole frame), halos recomputed from a wider level-0 "
+                        "halo; " + ("every rank runs the stream pipeline on its block and forms the shift vectors from its own top-left patch: no byte "
+                                    "crosses xGMI on the data path" if stream_like else "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair"))
+        if args.iters > 1:
+            steps_what = (f"shift launch + tick (iteration 1 of {fps} pairs, the new frames' pyramids, the pairs' corner chains) + {args.iters - 1} accumulating launches"
+                          if stream_like else f"pyramid + corner + {args.iters} LK launches + shift")
+        else:
+            steps_what = "one launch" if stream_like else "three launches"
         out = {
             "metric": "Mpix/s dense LK flow",
             "value": round(fps * w * h / (ms * 1e-3) / 1e6, 1),
@@ -991,44 +1215,22 @@ class Run:
             "data": "synthetic",
             "self_check": "skipped" if check_msg.startswith("SKIPPED") else "ok",
             "config": {
-                "untimed_clock_ramp_s": self.ramp_s, "warmup_steps_run": args.warmup,
-                "step": (f"one tick of the stream pipeline = one launch = {fps} frames (pairs): K = {args.steps} steps are {args.steps * fps} pairs"
-                         if stream_like else "one frame pair"),
                 "workload": f"{w}x{h} pair, {levels}-level pyramid, {window}x{window} window, iters={args.iters} "
-                            f"({'the only value the reference defines' if args.iters <= 1 else 'extension: bilinear-warp refinement, DESIGN.md lk_iter'}), "
-                            f"mode {args.mode}: new frame's pyramid + every LK level, inputs resident in HBM; {frames_what}",
-                "frames": (("four resident device buffers, " + ("read in place (ofx_params.borrow_frames)" if driver is None and args.path == "plain"
-                                                                   and args.borrow and w % 64 == 0 else "level 0 copied into the session per pair"))
-                           if not stream_like else f"a ring of {self.ring_n} distinct device buffers, " +
-                           (f"read in place (ofx_params.borrow_frames: a buffer stays unmodified for {(2 if args.two_stage else 3) * args.batch} further submits)"
-                            if borrowed else "level 0 copied into the session")),
-                "sharding": "none" if driver is None else (
-                    f"row blocks over {self.world} rank(s), halos recomputed from a wider level-0 halo; " +
-                    ("every rank runs the one-launch stream pipeline on its block and forms the shift vectors from its own top-left "
-                     "patch of the frame: no collective on the data path (DESIGN.md section 5)" if stream_like else
-                     "rank 0's corner kernel + one RCCL broadcast of the shift vectors per pair (DESIGN.md section 5)"))
-                    .replace("halos recomputed from a wider level-0 halo", "halo rows of every level exchanged with the neighbouring ranks"
-                             if args.shard_halo == "exchange" else "halos recomputed from a wider level-0 halo"),
+                            f"({'the only value the reference defines' if args.iters <= 1 else 'BASELINE.json config as written; iterations = extension lk_iter: bilinear-warp refinement, iteration 1 = the reference bit for bit'}), "
+                            f"mode {args.mode}, {'stream path' if stream_like else args.path + ' path'}: new frame's pyramid + every LK level"
+                            f"{' and iteration' if args.iters > 1 else ''}, inputs resident in HBM; {frames_what}",
+                "untimed_clock_ramp_s": self.ramp_s, "warmup_steps_run": args.warmup,
+                "step": (f"one tick of the stream pipeline = {fps} frames (pairs) = {steps_what}: K = {args.steps} steps are {args.steps * fps} pairs"
+                         if stream_like else f"one frame pair ({steps_what})"),
+                "frames": frames_cfg,
+                "sharding": sharding,
                 "self_check": check_msg,
             },
-            "roofline": {
-                "bound": "hbm", "kernel": kernel,
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "algorithmic_bytes_per_launch": lk_bytes, "pairs_per_launch": pairs_per_launch, "avg_launch_us": round(k_avg_us, 2), "min_launch_us": round(k_min_us, 2),
-                "launches_timed": k_n, "timed_in": "second pass over the same steps with hipEventRecord around each launch on its stream",
-                "traffic": traffic, "traffic_source": traffic_source,
-            },
+            "roofline": dict(dom, timed_in="second pass over the same steps with hipEventRecord around each launch on its stream", traffic=traffic, **traffic_src),
         }
-        if iters_pair is not None:
-            out["roofline"].update(iters_pair)
-            out["roofline"]["kernel"] = (f"all launches of a pair with {args.iters} iterations (stream tick / LK, shift, {args.iters - 1} x warp, "
-                                         f"{args.iters - 1} x accumulating LK); avg_launch_us = kernel time per pair")
+        out["roofline"]["whole_pair"] = whole
         if self.rccl_world is not None:
             out["rccl_world"] = self.rccl_world   # sum of ones over the communicator: the ranks RCCL actually connected
-        if not stream_like:
-            # pair-at-a-time paths: every launch of a pair, event-timed in the same second pass
-            out["roofline"]["launches_per_pair_us"] = {k: round(v[0], 2) for k, v in self.kinds.items() if v[2]}
         if extra:
             out["extra"] = extra
         return out
@@ -1036,6 +1238,12 @@ class Run:
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))   # (nothing above has imported torch or made a HIP call)
+    if os.environ.get("OFX_BENCH_RANK_PROBE") == "1":   # tests/test_bench_launch.py: how far the launch got, without a GPU
+        print(json.dumps({"probe": "rank", "rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")),
+                          "gpus": args.gpus, "iters": args.iters, "shard_halo": args.shard_halo}), file=sys.stderr, flush=True)
+        return
     plan_stream(args)
     run = Run(args)
     run.build_headline()

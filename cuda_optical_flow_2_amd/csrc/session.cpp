@@ -75,6 +75,7 @@ struct ofx_session {
     const uint8_t *bframe[kSets]{}; // borrow_frames: the caller's buffer behind image set i (level 0 is read from there)
     int bpitch[kSets]{};
     long reported = 0;                   // highest pair reported complete by the stream pipeline
+    long corner_newest = 0;              // highest pair whose corner stage has been enqueued (ofx_session_pair_status)
     float *uv = nullptr;        // 2 floats per level
     uint8_t *staging = nullptr; // one tightly packed 3ch level-0 frame for host uploads
     void *arena = nullptr;
@@ -94,7 +95,7 @@ template <typename F>
 static int timed_launch(ofx_session *s, int kind, void *stream, F &&launch)
 {
     static const char *const names[OFX_TIME_KINDS] = {"ofx.lk_levels", "ofx.lk_levels_accumulate", "ofx.warp_levels", "ofx.stream_tick",
-                                                      "ofx.shift_levels", "ofx.corner_flows", "ofx.pyramid"};
+                                                      "ofx.shift_levels", "ofx.corner_flows", "ofx.pyramid", "ofx.lk_levels_accumulate_warp"};
     OfxRange range(names[kind]); // (roctx, OFX_ROCTX=1: the launch's enqueue on the host side of a --marker-trace timeline)
     const bool timed = s->timing && s->ev_used + 2 <= s->ev.size();
     if (timed) OFX_HIP(hipEventRecord(s->ev[s->ev_used], ofx_stream(stream)));
@@ -150,6 +151,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(!p->stream_two_stage || p->borrow_frames, "ofx_session_create: stream_two_stage needs borrow_frames (the corner stage reads "
                                                             "both frames of a pair in the tick in which the second one arrives)");
     OFX_REQUIRE(p->iters <= 1 || p->mode != OFX_MODE_COMPAT_CPU, "ofx_session_create: refinement iterations need mode lk_float");
+    OFX_REQUIRE(!p->frames_partial || (p->sharded && p->local_corner && !p->stream_two_stage),
+                "ofx_session_create: frames_partial describes the frames of a sharded local_corner session (not stream_two_stage)");
     OFX_REQUIRE(p->iters <= 1 || !p->sharded || p->local_corner,
                 "ofx_session_create: refinement iterations on a sharded session run through the stream pipeline, which needs local_corner");
     OFX_REQUIRE((p->width >> (p->levels - 1)) > 0 && (p->height >> (p->levels - 1)) > 0,
@@ -255,7 +258,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         // target (radius + 3 pixels of stencils + the plane's first column / row); a smaller patch (patch_size) keeps the
         // status bit.
         const int need_r = (p->window >> 1) + 5;
-        s->repair = p->borrow_frames && p->levels >= 3 && (s->pw[lc] >= need_r || s->pw[lc] >= s->w[lc]) && (s->ph[lc] >= need_r || s->ph[lc] >= s->h[lc]);
+        s->repair = p->borrow_frames && !p->frames_partial && p->levels >= 3 && (s->pw[lc] >= need_r || s->pw[lc] >= s->w[lc]) && (s->ph[lc] >= need_r || s->ph[lc] >= s->h[lc]);
     }
     if (s->repair) {
         // Test hook: pretend the top-left patch planes are only this many level-0 pixels wide and high (never less than the
@@ -327,6 +330,11 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     s->staging = p->sharded ? nullptr : base + off_staging;
     // OFX_ITER_FUSED=0 keeps one ofx_warp_levels launch per refinement iteration
     s->fused_iters = p->iters > 1 && [] { const char *e = getenv("OFX_ITER_FUSED"); return !e || atoi(e) != 0; }();
+    // the launches that also write the warped image run on 32-bit buffer offsets (lk_body_buf.h): a session whose level 0 reaches
+    // 2 GB of plane or of flow rows keeps the warp launch + the old accumulating march, as before round 3
+    if ((size_t)(s->buf1[0] - s->buf0[0]) * (size_t)s->pitch[0] >= ((size_t)1 << 31) ||
+        (size_t)(s->buf1[0] - s->buf0[0]) * (size_t)s->w[0] * 8 >= ((size_t)1 << 31))
+        s->fused_iters = false;
     repoint(s);
     *out = s;
     return OFX_OK;
@@ -521,7 +529,7 @@ extern "C" int ofx_session_timing_read(ofx_session *s, double *avg_us, double *m
 {
     OFX_REQUIRE(s && avg_us && launches, "ofx_session_timing_read: bad arguments");
     // the dominant launches: the fused LK launches of the pair-at-a-time paths, the stream tick of the stream pipeline
-    OFX_TRY(timing_stats(s, (1u << OFX_TIME_LK) | (1u << OFX_TIME_LK_ACC) | (1u << OFX_TIME_STREAM), avg_us, min_us, launches));
+    OFX_TRY(timing_stats(s, (1u << OFX_TIME_LK) | (1u << OFX_TIME_LK_ACC) | (1u << OFX_TIME_LK_ACC_WARP) | (1u << OFX_TIME_STREAM), avg_us, min_us, launches));
     s->ev_used = 0;
     return OFX_OK;
 }
@@ -551,7 +559,7 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
 // one multi-level LK launch, bracketed by timing events when the session is armed (ofx_session_timing)
 static int timed_lk_launch(ofx_session *s, const ofx_lk_desc *lk, int nl, void *stream)
 {
-    return timed_launch(s, lk[0].accumulate ? OFX_TIME_LK_ACC : OFX_TIME_LK, stream,
+    return timed_launch(s, lk[0].accumulate ? (lk[0].d_warp_out ? OFX_TIME_LK_ACC_WARP : OFX_TIME_LK_ACC) : OFX_TIME_LK, stream,
                         [&] { return ofx_lk_levels(lk, nl, s->p.window, s->p.mode, stream); });
 }
 
@@ -812,6 +820,8 @@ extern "C" int ofx_session_pair_status(ofx_session *s, int pair, int *h_status, 
     OFX_REQUIRE(s && h_status, "ofx_session_pair_status: null argument");
     const int slots = 2 * (s->p.stream_batch >= 2 ? s->p.stream_batch : 1);
     OFX_REQUIRE(pair >= 1, "ofx_session_pair_status: pairs are counted from 1 (frame 0 -> frame 1)");
+    OFX_REQUIRE(pair <= s->corner_newest && pair > s->corner_newest - slots,
+                "ofx_session_pair_status: pair %d is not among the newest %d pairs whose corner stage has run (newest: %ld)", pair, slots, s->corner_newest);
     hipStream_t st = ofx_stream(stream);
     OFX_HIP(hipMemcpyAsync(h_status, s->pair_status + (pair % slots), sizeof(int), hipMemcpyDeviceToHost, st));
     OFX_HIP(hipStreamSynchronize(st));
@@ -906,6 +916,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
     for (long pc = f0 - (D - 1) * B; pc <= f0 - (D - 1) * B + B - 1; ++pc) { // corner(pair pc)
         if (pc < 1 || pc > last_frame) continue;
         const int slot_i = g.n_corner;
+        if (pc > s->corner_newest) s->corner_newest = pc;
         ofx_corner_stage &C = g.corner[g.n_corner++];
         C.levels = L;
         C.d_uv = uvslot(pc);
@@ -941,7 +952,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
             // (both frames of a pair come through the same API with the same pitch; a borrowed level 0 uses the caller's)
             if (s->p.local_corner) {
                 // (a borrowed level 0 is the whole frame: the chain may read all of it, and the repair rebuilds from it)
-                const bool whole0 = k == 0 && s->p.borrow_frames;
+                const bool whole0 = k == 0 && s->p.borrow_frames && !s->p.frames_partial; // (partial frames: the patch's extent only)
                 const int rows_k = whole0 ? s->h[0] : chain_extent(k, s->ph[k]);
                 ofx_geom pg{s->w[k], s->h[k], pitch_of(pc, k, true), 0, rows_k, 0, rows_k};
                 C.level[k] = ofx_lk_desc{patch_of(pc - 1, k), patch_of(pc, k), pg, nullptr, 0, nullptr, 0, s->p.min_det};
@@ -1068,7 +1079,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
             }
             if (ns) OFX_TRY(timed_launch(s, OFX_TIME_SHIFT, stream, [&] { return ofx_shift_levels(sd, ns, stream); }));
             if (need_warp) OFX_TRY(timed_launch(s, OFX_TIME_WARP, stream, [&] { return ofx_warp_levels(wd, nw, stream); }));
-            OFX_TRY(timed_launch(s, OFX_TIME_LK_ACC, stream, [&] { return ofx_lk_levels(ld, nw, s->p.window, s->p.mode, stream); }));
+            OFX_TRY(timed_launch(s, wout ? OFX_TIME_LK_ACC_WARP : OFX_TIME_LK_ACC, stream, [&] { return ofx_lk_levels(ld, nw, s->p.window, s->p.mode, stream); }));
         }
     }
     s->stream_n = f0 + B;
@@ -1090,6 +1101,7 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
     s->stream_frames = -1;
     s->n_held = 0;
     s->reported = 0;
+    s->corner_newest = 0;
     s->have_prev = s->have_next = s->staged = false;
     for (int k = 0; k < s->p.levels; ++k) s->flow[k] = s->flowset[0][k];
     return OFX_OK;

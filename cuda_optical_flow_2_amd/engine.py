@@ -80,7 +80,7 @@ class Session:
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
                  shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False,
-                 min_det: float = 0.0, two_stage: bool = False, strict: bool = True):
+                 min_det: float = 0.0, two_stage: bool = False, strict: bool = True, frames_partial: bool = False):
         """strict: stream_drain() raises OfxError when the pipeline has drained and the session's status word is not 0 -- a pair
         whose result is NOT the reference's (a corner shift that left the patch of a session that cannot repair it, a shift or
         warp beyond a shard's halo; include/ofx.h, ofx_session_corner_status).  strict=False: poll corner_status() yourself."""
@@ -96,6 +96,7 @@ class Session:
         p.borrow_frames = int(bool(borrow_frames))
         p.min_det = float(min_det)
         p.stream_two_stage = int(bool(two_stage))
+        p.frames_partial = int(bool(frames_partial))   # (ofx_params.frames_partial: only the plan's rows + the patch were ever written)
         self.shard = shard
         if shard is not None:
             p.sharded = 1
@@ -252,7 +253,7 @@ class Session:
         check(self.L.ofx_session_timing_read(self._h, C.byref(avg), C.byref(mn), C.byref(n)), "session_timing_read")
         return avg.value, mn.value, n.value
 
-    TIME_KINDS = {"lk": 0, "lk_acc": 1, "warp": 2, "stream": 3, "shift": 4, "corner": 5, "pyramid": 6}   # OFX_TIME_*
+    TIME_KINDS = {"lk": 0, "lk_acc": 1, "warp": 2, "stream": 3, "shift": 4, "corner": 5, "pyramid": 6, "lk_acc_warp": 7}   # OFX_TIME_*
 
     def timing_read_kind(self, kind: str):
         """(average us, minimum us, launches) of one kind of launch; call before timing_read, which re-arms."""

@@ -121,9 +121,12 @@ class HipBackend:
         from . import engine
 
         self.plan = plan
+        # "stream_exchange": a rank's frame buffers hold its plan's rows and the top-left patch, nothing else -- the session must
+        # not repair a corner shift from rows that never arrived (ofx_params.frames_partial: the status bit stays an error)
         self.session = engine.Session(plan.width, plan.height, plan.levels, plan.window, mode, device=device, shard=plan,
                                       local_corner=local_corner, patch_size=patch_size, stream_batch=stream_batch,
-                                      borrow_frames=borrow_frames, iters=plan.iters)
+                                      borrow_frames=borrow_frames, iters=plan.iters,
+                                      frames_partial=plan.halo_mode == "stream_exchange")
         self._views = {}
         # the collective runs on a torch-allocated staging tensor (RCCL then only ever sees caching-allocator memory)
         self.uv_stage = self.uv_all.new_zeros(self.uv_all.shape)
@@ -256,62 +259,85 @@ class ShardedFlow:
         return self._xlists
 
     def assemble_frames(self, own_rows, buffers):
-        """own_rows[i]: this rank's rows [own0, own1) of frame i (tensor [rows, width]); buffers[i]: a frame-shaped tensor
-        [height, >= width] that receives them, the halo rows and the patch.  One batched group of P2P operations for all
-        frames (RCCL over xGMI on GPUs, gloo in the CPU tests).  Rows the plan does not hold are left untouched."""
+        """own_rows: this rank's rows [own0, own1) of the n frames of a tick -- a sequence of [rows, width] tensors or one stacked
+        [n, rows, width] tensor; buffers: n frame-shaped tensors [height, >= width] (a sequence, or one stacked [n, height, width]
+        tensor) that receive them, the halo rows and the patch.  ONE message per peer and direction carries the pieces of all n
+        frames (halo rows, patch rows / columns), all of them in one batched group of P2P operations (RCCL over xGMI on GPUs, gloo
+        in the CPU tests).  Rows the plan does not hold are left untouched."""
+        import torch
         import torch.distributed as dist
 
         p = self.plan
         o0, o1 = p.own[0]
+        stack = own_rows if hasattr(own_rows, "dim") and own_rows.dim() == 3 else torch.stack(list(own_rows))
+        n = stack.shape[0]
+        assert tuple(stack.shape[1:]) == (o1 - o0, p.width), (tuple(stack.shape), (o1 - o0, p.width))
+        stacked_out = hasattr(buffers, "dim") and buffers.dim() == 3
+
+        def put(a, b, cols, block):   # block [n, b - a, cols] -> rows [a, b), columns [0, cols) of every buffer
+            if stacked_out:
+                buffers[:, a:b, :cols] = block   # one copy for all n frames
+            else:
+                for i, buf in enumerate(buffers):
+                    buf[a:b, :cols] = block[i]
+
+        put(o0, o1, p.width, stack)
+        if self.world == 1:
+            return
         recv, send = self._exchange_lists()
-        ops, keep = [], []
-        for rows, buf in zip(own_rows, buffers):
-            assert tuple(rows.shape) == (o1 - o0, p.width), (tuple(rows.shape), (o1 - o0, p.width))
-            buf[o0:o1, :p.width] = rows
-            if self.world == 1:
-                continue
-            for peer, a, b, cols in send:
-                ops.append(dist.P2POp(dist.isend, rows[a - o0: b - o0, :cols].contiguous(), peer))
-            for peer, a, b, cols in recv:
-                t = rows.new_empty((b - a, cols))
-                ops.append(dist.P2POp(dist.irecv, t, peer))
-                keep.append((buf, a, b, cols, t))
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        for buf, a, b, cols, t in keep:
-            buf[a:b, :cols] = t
+        ops, inbox = [], []
+        for peer in sorted({x[0] for x in send}):
+            parts = [stack[:, a - o0: b - o0, :cols].reshape(-1) for pr, a, b, cols in send if pr == peer]
+            ops.append(dist.P2POp(dist.isend, parts[0].contiguous() if len(parts) == 1 else torch.cat(parts), peer))
+        for peer in sorted({x[0] for x in recv}):
+            pieces = [(a, b, cols) for pr, a, b, cols in recv if pr == peer]
+            t = stack.new_empty((n * sum((b - a) * cols for a, b, cols in pieces),))
+            ops.append(dist.P2POp(dist.irecv, t, peer))
+            inbox.append((pieces, t))
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        for pieces, t in inbox:
+            off = 0
+            for a, b, cols in pieces:
+                cnt = n * (b - a) * cols
+                put(a, b, cols, t[off: off + cnt].view(n, b - a, cols))
+                off += cnt
 
     def _frame_buffers(self, n, like):
-        """a ring of frame-shaped buffers for the assembled frames (borrowed frames stay in use for several ticks)"""
-        if not hasattr(self, "_ring"):
-            self._ring, self._ring_i = [], 0
-        need = 4 * max(n, 1) + 2
-        while len(self._ring) < need:
-            self._ring.append(like.new_zeros((self.plan.height, self.plan.width)))
-        out = [self._ring[(self._ring_i + i) % len(self._ring)] for i in range(n)]
-        self._ring_i = (self._ring_i + n) % len(self._ring)
-        return out
+        """n frame-shaped buffers for the assembled frames of a tick, as one stacked [n, height, width] tensor out of a ring of
+        groups (borrowed frames stay in use for three ticks: five groups)"""
+        key = int(n)
+        if not hasattr(self, "_rings"):
+            self._rings = {}
+        if key not in self._rings:
+            self._rings[key] = [like.new_zeros((5, key, self.plan.height, self.plan.width)), 0, {}]
+        ring = self._rings[key]
+        g = ring[1]
+        ring[1] = (g + 1) % ring[0].shape[0]
+        return ring[0][g], g, ring[2]
 
     def stream_submit_own_rows(self, own_rows) -> int:
-        """A tick's frames as this rank's own rows only: assemble (exchange) and submit to the stream pipeline."""
-        bufs = self._frame_buffers(len(own_rows), own_rows[0])
+        """A tick's frames as this rank's own rows only ([n, rows, width] or a sequence): assemble (one exchange) and hand the
+        buffers to the stream pipeline in one call."""
+        from . import engine
+
+        first = own_rows[0]
+        bufs, g, groups = self._frame_buffers(len(own_rows), first)
         self.assemble_frames(own_rows, bufs)
-        done = -1
-        for b in bufs:
-            done = max(done, self.session.stream_submit(b))
-        return done
+        if g not in groups:   # (the argument block of a ring group, packed once)
+            groups[g] = engine.FrameGroup([bufs[i] for i in range(bufs.shape[0])])
+        return self.session.stream_submit_frames(groups[g])
 
     def push_own_rows(self, rows):
         """pair-at-a-time form (the CPU stand-in of the tests): priming with this rank's own rows of the first frame"""
-        (buf,) = self._frame_buffers(1, rows)
-        self.assemble_frames([rows], [buf])
-        self.push_frame(buf)
+        bufs, _, _ = self._frame_buffers(1, rows)
+        self.assemble_frames([rows], bufs)
+        self.push_frame(bufs[0])
 
     def step_own_rows(self, rows):
-        (buf,) = self._frame_buffers(1, rows)
-        self.assemble_frames([rows], [buf])
-        self.step(buf)
+        bufs, _, _ = self._frame_buffers(1, rows)
+        self.assemble_frames([rows], bufs)
+        self.step(bufs[0])
 
     def push_frame(self, frame):
         """Make `frame` the previous frame (priming, main.cu:203-209)."""

@@ -412,7 +412,12 @@ typedef struct ofx_params {
      * leaves the patch (256 level-0 pixels or patch_size) is read through a patch pyramid the corner block rebuilds around it
      * (ofx_corner_stage.d_patch_reloc; ofx_session_pair_status says for which pairs that happened). */
     int stream_two_stage;
-    int reserved[1];
+    /* The frame buffers handed to this (sharded, local_corner) session are PARTIAL: only the level-0 rows the plan holds
+     * (buf_y0[0] .. buf_y1[0]) and the frame's top-left patch were ever written; every other byte is undefined (the ranks of
+     * parallel.ShardedFlow's "stream_exchange" mode only ever receive those).  The corner chain then reads level 0 through the
+     * patch's extent only and the repair of a shift that leaves the patch is OFF (it would rebuild from rows that are not
+     * there): such a pair raises bit k of the status word, as with copied frames, and is an error.  Not with stream_two_stage. */
+    int frames_partial;
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);
@@ -424,7 +429,8 @@ int ofx_session_corner_status(ofx_session *s, int *h_status, void *stream);
 /* The same word for ONE pair of the stream pipeline (frames counted from 0, pair p = frame p-1 -> frame p), while it is one of
  * the newest 2 * stream_batch pairs whose corner stage has run: the bits that pair raised, plus OFX_STATUS_REPAIRED when its
  * shifted corner left the top-left patch and was read through a relocated one (informational: the flow is the reference's).
- * With the repair in place (stream_two_stage, or local_corner with borrow_frames) bit k can no longer occur; bits 8 + k and
+ * With the repair in place (stream_two_stage, or local_corner with borrow_frames and whole frames: not frames_partial) bit k can
+ * no longer occur; bits 8 + k and
  * 16 + k (a shard's halo) stay errors.  Synchronises `stream`; does not clear anything. */
 int ofx_session_pair_status(ofx_session *s, int pair, int *h_status, void *stream);
 int ofx_session_destroy(ofx_session *s);
@@ -506,7 +512,8 @@ int ofx_session_timing_read(ofx_session *s, double *avg_us, double *min_us, int 
 #define OFX_TIME_SHIFT 4   /* stand-alone global shift of all levels (refinement iterations only) */
 #define OFX_TIME_CORNER 5  /* corner kernel */
 #define OFX_TIME_PYRAMID 6 /* fused pyramid launch */
-#define OFX_TIME_KINDS 7
+#define OFX_TIME_LK_ACC_WARP 7 /* the same launch when it also writes the next iteration's warped image (lk_body_warp.h) */
+#define OFX_TIME_KINDS 8
 int ofx_session_timing_read_kind(ofx_session *s, int kind, double *avg_us, double *min_us, int *launches);
 
 /* ---- host-pointer convenience used by the gpu:: compat surface ------------ */

@@ -626,7 +626,7 @@ def test_sharded_stream_sessions_read_only_their_rows_and_the_patch(eng, cfg):
             t[b0:b1] = f[b0:b1]
             t[:ph, :pw] = f[:ph, :pw]
             bufs.append(t)
-        s = eng.Session(w, h, L, win, "lk_float", shard=pl, local_corner=True, stream_batch=B, borrow_frames=borrow)
+        s = eng.Session(w, h, L, win, "lk_float", shard=pl, local_corner=True, stream_batch=B, borrow_frames=borrow, frames_partial=True)
         got[r] = _stream_all_pairs(s, bufs, L, B)
         assert s.corner_status() == 0
         s.close()
@@ -680,6 +680,46 @@ def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
         assert s.corner_status() == 0   # reading clears it
         seen_miss = seen_miss or got != 0
         s.close()
+    assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
+
+
+def test_partial_frames_report_a_shift_that_leaves_the_patch_instead_of_repairing_it(eng):
+    """a rank of ShardedFlow's "stream_exchange" mode holds its plan's rows and the top-left patch of a frame,
+    nothing else.  With borrowed frames the session used to REPAIR a corner shift that leaves the patch by rebuilding the patch
+    pyramid around the target from the whole next frame -- here from bytes that never arrived -- and said nothing.  With
+    ofx_params.frames_partial the repair is off and the pair raises bit k, exactly the bits a session with copied frames (which
+    cannot repair either) raises on the whole frames; the poison outside the rows and the patch must not change them."""
+    import torch
+    from cuda_optical_flow_2_amd.parallel import ShardPlan
+
+    w, h, L, win, patch = 640, 480, 3, 3, 12
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    base = xx / 2 + yy / 3 + xx * yy / 64
+    seen_miss = False
+    for d in (20, 80):
+        a = np.clip(np.floor(base), 0, 255).astype(np.uint8)
+        b = np.clip(np.floor(base + d), 0, 255).astype(np.uint8)
+        seq = [torch.from_numpy(f).cuda() for f in (a, b, a, b)]
+        ref = eng.Session(w, h, L, win, "lk_float", local_corner=True, patch_size=patch, strict=False)   # copied whole frames: reports, cannot repair
+        _stream_all_pairs(ref, seq, L, 1)
+        want_bits = ref.corner_status() & ((1 << L) - 1)
+        ref.close()
+        for r in range(2):
+            pl = ShardPlan(w, h, L, win, r, 2, halo_mode="stream_exchange")
+            pw, ph = pl.patch_wh(patch)
+            b0, b1 = pl.buf[0]
+            bufs = []
+            for f in seq * 2:   # (distinct buffers: borrowed frames stay in use for three ticks)
+                t = torch.full((h, w), 0xEE, dtype=torch.uint8, device="cuda")
+                t[b0:b1] = f[b0:b1]
+                t[:ph, :pw] = f[:ph, :pw]
+                bufs.append(t)
+            s = eng.Session(w, h, L, win, "lk_float", shard=pl, local_corner=True, patch_size=patch, borrow_frames=True, frames_partial=True, strict=False)
+            _stream_all_pairs(s, bufs[:4], L, 1)
+            got_bits = s.corner_status()
+            s.close()
+            assert got_bits & ((1 << L) - 1) == want_bits, (d, r, hex(got_bits), hex(want_bits))
+        seen_miss = seen_miss or want_bits != 0
     assert seen_miss, "no brightness step drove the corner shift out of the patch: the test lost its subject"
 
 

@@ -257,8 +257,7 @@ def _rank_main(rank, world, port, cfg, mode, corner="broadcast", halo_mode="reco
 
         if halo_mode == "stream_exchange":
             sf._frame_buffers(1, own_rows(frames[0]))
-            for b in sf._ring:
-                b.fill_(0xEE)   # whatever the exchange does not bring stays poison
+            sf._rings[1][0].fill_(0xEE)   # whatever the exchange does not bring stays poison
             sf.push_own_rows(own_rows(frames[0]))
         else:
             sf.push_frame(seen_by_rank(frames[0]))
@@ -350,3 +349,45 @@ def test_exchange_plan_invariants():
             assert p.comp == p.own and p.buf == p.need
     with pytest.raises(ValueError):
         ShardPlan(96, 144, 3, 5, 0, 4, 8, "exchange")   # 9 coarse rows per rank < halo 11: a neighbour's halo would span two ranks
+
+
+def _rank_assemble(rank, world, port):
+    """a tick of THREE frames through ShardedFlow.assemble_frames in its stacked form (one message per peer and direction): every
+    buffer must hold the frame's rows of the plan and its top-left patch, and poison everywhere else"""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w, h, L, win = 96, 144, 3, 5
+        plan = ShardPlan(w, h, L, win, rank, world, 8, "stream_exchange")
+        sf = ShardedFlow(w, h, L, win, "lk_float", rank, world, margin=8, backend=OracleBackend(plan, "lk_float", patch_size=48),
+                         corner="local", halo_mode="stream_exchange", patch_size=48)
+        frames = [synth.random_pair(w, h, 40 + i)[0] for i in range(3)]
+        o0, o1 = plan.own[0]
+        stack = torch.from_numpy(np.stack([f[o0:o1] for f in frames]))
+        bufs = torch.full((3, h, w), 0xEE, dtype=torch.uint8)
+        sf.assemble_frames(stack, bufs)
+        pw, ph = plan.patch_wh(48)
+        b0, b1 = plan.buf[0]
+        for i, f in enumerate(frames):
+            want = np.full((h, w), 0xEE, np.uint8)
+            want[b0:b1] = f[b0:b1]
+            want[:ph, :pw] = f[:ph, :pw]
+            assert np.array_equal(bufs[i].numpy(), want), f"rank {rank}/{world} frame {i}"
+        # the list form (the pair-at-a-time callers) brings the same bytes
+        bufs2 = [torch.full((h, w), 0xEE, dtype=torch.uint8) for _ in frames]
+        sf.assemble_frames([torch.from_numpy(f[o0:o1].copy()) for f in frames], bufs2)
+        for i in range(3):
+            assert torch.equal(bufs2[i], bufs[i])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_assemble_frames_of_a_tick_in_one_exchange_gloo(world):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rank_assemble, args=(world, _free_port()), nprocs=world, join=True)
