@@ -141,9 +141,10 @@ def test_timing_kinds_cover_every_launch_of_a_pair(eng, monkeypatch):
 
     w, h, L, win = 640, 480, 3, 9
     p, n = synth.smooth_pair(w, h, 1.0, 0.5)
-    for iters, fused, want in ((1, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 0, "warp": 0, "shift": 0}),
-                               (3, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "warp": 0, "shift": 1}),
-                               (3, "0", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "warp": 2, "shift": 1})):
+    # (lk_acc_warp: an accumulating launch that also writes the next iteration's warped image -- every one but the last)
+    for iters, fused, want in ((1, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 0, "lk_acc_warp": 0, "warp": 0, "shift": 0}),
+                               (3, "1", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 1, "lk_acc_warp": 1, "warp": 0, "shift": 1}),
+                               (3, "0", {"pyramid": 1, "corner": 1, "lk": 1, "lk_acc": 2, "lk_acc_warp": 0, "warp": 2, "shift": 1})):
         monkeypatch.setenv("OFX_ITER_FUSED", fused)
         s = eng.Session(w, h, L, win, "lk_float", iters=iters)
         s.push_frame_host(p)
@@ -155,5 +156,5 @@ def test_timing_kinds_cover_every_launch_of_a_pair(eng, monkeypatch):
             assert cnt == count, (iters, kind, cnt)
             assert count == 0 or (0 < mn <= avg < 1e5)
         avg, mn, cnt = s.timing_read()
-        assert cnt == want["lk"] + want["lk_acc"]
+        assert cnt == want["lk"] + want["lk_acc"] + want["lk_acc_warp"]
         s.close()
