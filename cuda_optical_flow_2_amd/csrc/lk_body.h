@@ -1058,6 +1058,7 @@ __device__ __forceinline__ void lk_wave_impl(const LkTable &T, int wave, int lan
 } // namespace ofx_dev
 #include "lk_body_warp.h" // the warp of lk_iter in two stages (ITER == 2 below)
 #include "lk_body_buf.h" // lk_wave_buf: the same march on buffer resources (a fifth of the scalar instructions)
+#include "lk_body_wide.h" // lk_wave_wide: eight columns per lane (round 4)
 namespace ofx_dev {
 
 // One wave of the fused level kernel: picks the variant for its tile (wave-uniform: two complete copies of the march, nothing

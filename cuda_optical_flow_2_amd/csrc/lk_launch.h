@@ -62,11 +62,20 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 #define OFX_ITER_MIN_WAVES(ITER) 3
 #endif
 // DMA: the rows are fetched two steps ahead through LDS (lk_body_buf.h; chosen per launch as for the stream kernel)
-template <int R, int MODE, bool FAST, int ITER, bool DMA = false>
-__global__ __launch_bounds__(64, OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
+// NC = 8: the march with eight columns per lane (lk_body_wide.h; no deep fetch)
+#ifndef OFX_WIDE_ITER_MIN_WAVES
+#define OFX_WIDE_ITER_MIN_WAVES 2
+#endif
+template <int R, int MODE, bool FAST, int ITER, bool DMA = false, int NC = 4>
+__global__ __launch_bounds__(64, NC == 8 ? OFX_WIDE_ITER_MIN_WAVES : OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t xlds[DMA ? kLkWaveLdsDma : kLkWaveLds];
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLds)];
     const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if constexpr (NC == 8) {
+        static_assert(!DMA, "the wide march has no deep fetch");
+        lk_wave_w<R, MODE, FAST, ITER, 8>(T, wave, lane, xlds);
+        return;
+    }
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
     while (hi - level > 1) {
@@ -111,8 +120,12 @@ using ofx_launch::g_trace_header;
 // DMA: the LK stage fetches its rows two steps ahead through LDS (lk_body_buf.h); chosen per launch by launch_stream_r
 // WOUT: the LK stage is iteration 1 of pairs that have more (lk_iter): it also writes the warped images of their second iteration
 // (lk_body_buf.h, ITER = WOUT = 3, or 5 on the row windows of a shard; ~128 VGPRs: three blocks per CU at least); 0: it does not
-template <int R, int MODE, bool FAST, bool DMA, int WOUT = 0>
-__global__ __launch_bounds__(256, WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE)) void stream_kernel(const StreamArgs S)
+// NC = 8: the LK stage marches with eight columns per lane (lk_body_wide.h): ~170 VGPRs, OFX_WIDE_MIN_BLOCKS blocks per CU
+#ifndef OFX_WIDE_MIN_BLOCKS
+#define OFX_WIDE_MIN_BLOCKS 3
+#endif
+template <int R, int MODE, bool FAST, bool DMA, int WOUT = 0, int NC = 4>
+__global__ __launch_bounds__(256, NC == 8 ? (WOUT ? 2 : OFX_WIDE_MIN_BLOCKS) : (WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE))) void stream_kernel(const StreamArgs S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int b = (int)blockIdx.x, tid = (int)threadIdx.x;
@@ -134,7 +147,8 @@ __global__ __launch_bounds__(256, WOUT ? 3 : OFX_STREAM_MIN_BLOCKS(R, MODE)) voi
                                      reinterpret_cast<int *>(lds + kCornerScratch - 32));
         }
     } else if (b < S.first[0]) {
-        lk_wave<R, MODE, false, false, FAST, DMA, WOUT>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
+        if constexpr (NC == 8) lk_wave_w<R, MODE, FAST, WOUT, 8>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLdsW);
+        else lk_wave<R, MODE, false, false, FAST, DMA, WOUT>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -182,10 +196,10 @@ inline const double *lk_skew()
     return sk;
 }
 
-template <int R>
+template <int R, int NC = 4>
 int plan_table(const LkLevelIn *lv, int n, int capacity, LkTable *out)
 {
-    using G = TileGeom<R>;
+    using G = TileGeomW<R, NC>; // (NC = 4: TileGeom<R>)
     const int min_h = env_int("OFX_LK_MIN_STRIP", 8);
     const double *skew = lk_skew();
     const bool skewed = skew[0] != 1.0 || skew[1] != 1.0 || skew[2] != 1.0 || skew[3] != 1.0;
@@ -273,13 +287,13 @@ int launch_r(const LkLevelIn *lv, int n, hipStream_t st)
     return OFX_OK;
 }
 
-template <int R, int MODE, bool FAST, int ITER, bool DMA>
+template <int R, int MODE, bool FAST, int ITER, bool DMA, int NC = 4>
 int launch_iter_rd(const LkLevelIn *lv, int n, hipStream_t st)
 {
-    static const int capacity = lk_wave_target(lk_iter_kernel<R, MODE, FAST, ITER, DMA>, 64, 0, 0, 4);
+    static const int capacity = lk_wave_target(lk_iter_kernel<R, MODE, FAST, ITER, DMA, NC>, 64, 0, 0, NC == 8 ? env_int("OFX_WIDE_WAVES_PER_SIMD", 2) : 4);
     LkTable t{};
-    const int blocks = plan_table<R>(lv, n, capacity, &t);
-    hipLaunchKernelGGL((lk_iter_kernel<R, MODE, FAST, ITER, DMA>), dim3((unsigned)blocks), dim3(64), 0, st, t);
+    const int blocks = plan_table<R, NC>(lv, n, capacity, &t);
+    hipLaunchKernelGGL((lk_iter_kernel<R, MODE, FAST, ITER, DMA, NC>), dim3((unsigned)blocks), dim3(64), 0, st, t);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
 }
@@ -302,19 +316,20 @@ int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
 // two frames per launch: 279 vs 295 us (-5 %); 4K with its frames in the Infinity Cache: 247 vs 237 us (+4 %: the form costs
 // ~60 more scalar instructions per step, and the loads are short there) -- so it is chosen by the size of the largest level:
 // planes of 16 Mpx and more do not stay cached between their two uses.  OFX_LK_DMA=0 / 1 overrides.
-template <int R, int MODE, bool FAST, bool DMA, int WOUT>
+template <int R, int MODE, bool FAST, bool DMA, int WOUT, int NC = 4>
 int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
-    constexpr size_t wave_lds = DMA ? kLkWaveLdsDma : kLkWaveLds;
+    constexpr size_t wave_lds = NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLds);
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
     // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
-    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT>, 256, 4 * wave_lds, 1, 2);
-    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT>, 256, 4 * wave_lds, 1, 4);
+    // (eight columns per lane: a wave carries twice the pixels, and three blocks fit a CU: 1 / 2 waves per SIMD)
+    static const int capacity1 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT, NC>, 256, 4 * wave_lds, 1, NC == 8 ? 1 : 2);
+    static const int capacity2 = lk_wave_target(stream_kernel<R, MODE, FAST, DMA, WOUT, NC>, 256, 4 * wave_lds, 1, NC == 8 ? env_int("OFX_WIDE_WAVES_PER_SIMD", 2) : 4);
     int pairs = 0;
     for (int i = 0; i < n; ++i) pairs += (lv[i].a.w == lv[0].a.w && lv[i].a.h == lv[0].a.h) ? 1 : 0;
     const int capacity = pairs >= 2 ? capacity2 : capacity1;
     int lk_blocks = 0;
-    if (n > 0) lk_blocks = ofx_div_up(plan_table<R>(lv, n, capacity, &S.lk), 4);
+    if (n > 0) lk_blocks = ofx_div_up(plan_table<R, NC>(lv, n, capacity, &S.lk), 4);
     S.first[0] = OFX_STREAM_MAX_BATCH + lk_blocks;
     for (int i = 0; i < kPyrStages; ++i) S.first[i + 1] = S.first[i] + stage_blocks[i];
     const int blocks = S.first[kPyrStages];
@@ -329,9 +344,52 @@ int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage
     }
     if (lds < corner_lds) lds = corner_lds;
     if (lds < 4 * wave_lds) lds = 4 * wave_lds; // an LK block: four waves, each with its exchange row (and its fetched rows)
-    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST, DMA, WOUT>), dim3((unsigned)blocks), dim3(256), lds, st, S);
+    hipLaunchKernelGGL((stream_kernel<R, MODE, FAST, DMA, WOUT, NC>), dim3((unsigned)blocks), dim3(256), lds, st, S);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
+}
+
+// the same launches with eight columns per lane (one translation unit per family: lk_inst_*8.hip)
+template <int MODE, bool FAST, int WOUT = 0>
+int launch_stream_mode_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
+{
+    switch (radius) {
+    case 1: return launch_stream_rd<1, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 2: return launch_stream_rd<2, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 3: return launch_stream_rd<3, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 4: return launch_stream_rd<4, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 5: return launch_stream_rd<5, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 6: return launch_stream_rd<6, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 7: return launch_stream_rd<7, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 8: return launch_stream_rd<8, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 9: return launch_stream_rd<9, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 10: return launch_stream_rd<10, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    case 11: return launch_stream_rd<11, MODE, FAST, false, WOUT, 8>(lv, n, S, stage_blocks, lds, st);
+    default: break;
+    }
+    ofx_set_error("ofx_stream_launch: window %d not supported with eight columns per lane", 2 * radius + 1);
+    return OFX_E_UNSUPPORTED;
+}
+
+template <int MODE, bool FAST, int ITER>
+int launch_iter_mode_w8(int radius, const LkLevelIn *lv, int n, hipStream_t st)
+{
+    switch (radius) {
+    case 1: return launch_iter_rd<1, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 2: return launch_iter_rd<2, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 3: return launch_iter_rd<3, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 4: return launch_iter_rd<4, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 5: return launch_iter_rd<5, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 6: return launch_iter_rd<6, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 7: return launch_iter_rd<7, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 8: return launch_iter_rd<8, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 9: return launch_iter_rd<9, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 10: return launch_iter_rd<10, MODE, FAST, ITER, false, 8>(lv, n, st);
+    case 11: return launch_iter_rd<11, MODE, FAST, ITER, false, 8>(lv, n, st);
+    default: break;
+    }
+    ofx_set_error("ofx_lk_levels: window %d not supported with eight columns per lane", 2 * radius + 1);
+    return OFX_E_UNSUPPORTED;
 }
 
 template <int R, int MODE, bool FAST, int WOUT>
@@ -446,4 +504,7 @@ int stream_lk_float_fast_wout_rw(int radius, const LkLevelIn *lv, int n, StreamA
 int stream_lk_float(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
+// eight columns per lane (lk_body_wide.h)
+int stream_lk_float_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
+int stream_lk_float_fast_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 } // namespace ofx_launch

@@ -90,6 +90,23 @@ int lk_build_levels(const ofx_lk_desc *d, int n, int window, int mode, int32_t *
     return OFX_OK;
 }
 
+// Columns per lane of the LK march of a launch: 8 (lk_body_wide.h) or 4.  The wide march has no deep fetch, so launches that would
+// choose that (levels of 16 Mpx and more, launch_stream_r) keep four columns.  OFX_LK_COLS=4 / 8 overrides.
+#ifndef OFX_LK_COLS_DEFAULT
+#define OFX_LK_COLS_DEFAULT 4 // (measured, profiles/r04_ablation.txt: eight columns lose at 4K -- two LK waves per SIMD next to the pyramid stage)
+#endif
+int lk_cols(const LkLevelIn *lv, int m, int radius)
+{
+    static const int forced = [] { const char *e = getenv("OFX_LK_COLS"); return e ? atoi(e) : 0; }();
+    static const int dma_forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
+    if (radius < 1 || radius > 11 || m <= 0) return 4;
+    if (forced == 4 || forced == 8) return forced;
+    long max_px = 0;
+    for (int i = 0; i < m; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
+    if (dma_forced > 0 || (dma_forced < 0 && max_px >= 16l * 1000 * 1000)) return 4;
+    return OFX_LK_COLS_DEFAULT;
+}
+
 int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_sums, void *stream)
 {
     LkLevelIn lv[OFX_MAX_LK_ITEMS];
@@ -254,6 +271,9 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
         return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::stream_lk_float_fast_wout(window >> 1, lv, m, S, stage_blocks, lds, st)
                                               : ofx_launch::stream_lk_float_wout(window >> 1, lv, m, S, stage_blocks, lds, st);
     }
+    if (mode != OFX_MODE_COMPAT_CPU && lk_cols(lv, m, window >> 1) == 8)
+        return mode == OFX_MODE_LK_FLOAT_FAST ? ofx_launch::stream_lk_float_fast_w8(window >> 1, lv, m, S, stage_blocks, lds, st)
+                                              : ofx_launch::stream_lk_float_w8(window >> 1, lv, m, S, stage_blocks, lds, st);
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::stream_lk_float_fast(window >> 1, lv, m, S, stage_blocks, lds, st);
     return mode == OFX_MODE_LK_FLOAT ? ofx_launch::stream_lk_float(window >> 1, lv, m, S, stage_blocks, lds, st)
                                      : ofx_launch::stream_compat_cpu(window >> 1, lv, m, S, stage_blocks, lds, st);
