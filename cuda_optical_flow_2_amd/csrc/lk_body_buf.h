@@ -52,8 +52,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 #ifndef OFX_LK_DMA_ROWS
 #define OFX_LK_DMA_ROWS 1
 #endif
+// Deferred flow store (experiment; -DOFX_LK_DEFER_STORE=1): a step's output row stays in a SECOND exchange row
+// of LDS and is stored one step later, in the middle of the next step -- after that step's row loads have been issued, so that no
+// load queues behind the two 1 KB stores of the row before it.  Measured: profiles/r04_ablation.txt.
+// 0: never; 1: every launch of the buffer march; 2 (shipped): the accumulating launches of lk_iter only (ITER 1, 2, 4), whose step
+// holds the most memory operations (row loads, the old flow, eight warp taps, three stores): +2.3 % at 4K / 5 iterations; the
+// reference-defined tick measured 0 % (ring in the Infinity Cache) to -3 % (frames from HBM) with it and keeps the plain order.
+#ifndef OFX_LK_DEFER_STORE
+#define OFX_LK_DEFER_STORE 2
+#endif
+constexpr int kLkXRows = OFX_LK_DEFER_STORE ? 2 : 1;            // exchange rows per wave
+constexpr int kLkWaveLdsX = kLkXRows * kLkWaveLds;              // what a wave of the buffer march owns without the deep fetch
 constexpr int kLkDmaRowBytes = 256, kLkDmaRows = 6, kLkDmaSetBytes = kLkDmaRows * kLkDmaRowBytes;
-constexpr int kLkWaveLdsDma = kLkWaveLds + 2 * kLkDmaSetBytes; // the exchange row, then two sets of fetched rows
+constexpr int kLkWaveLdsDma = kLkWaveLdsX + 2 * kLkDmaSetBytes; // the exchange row(s), then two sets of fetched rows
 
 // ITER (refinement iterations of lk_iter): 0 = flow = result (the reference's level); 1 = flow += result,
 // the row's old flow fetched through the flow's own resource with the step's rows; 2 = the same, and the march also writes the
@@ -67,6 +78,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     using G = TileGeom<R>;
     constexpr int NS = 2 * R + 1;
     constexpr bool ACC = ITER == 1 || ITER == 2 || ITER == 4, WOUT = ITER >= 2, ROWWIN = ITER >= 4;
+    constexpr bool DEFER = OFX_LK_DEFER_STORE == 1 || (OFX_LK_DEFER_STORE == 2 && ACC);
 
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
@@ -233,7 +245,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     };
 
     // ---- DMA form: issue the six rows of a step into LDS set `set`; take them out again a step later
-    const uint32_t dma_base = (uint32_t)(uintptr_t)((lds_ptr)xlds + kLkWaveLds); // LDS byte address of set 0, row 0 (wave-uniform)
+    const uint32_t dma_base = (uint32_t)(uintptr_t)((lds_ptr)xlds + kLkWaveLdsX); // LDS byte address of set 0, row 0 (wave-uniform)
     uint32_t dma_lane = dma_base + 4u * (uint32_t)lane;                           // this lane's dword in set 0, row 0
     auto dma_load = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t voff, int soff, uint32_t lds_addr) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(uintptr_t)lds_addr, 4, voff, soff, 0, 0);
@@ -307,6 +319,34 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     pin_scalar(fso0);
     pin_scalar(fstep);
 
+    // the two streaming stores of output row (step s_row) from its chunks xlo / xhi of the exchanged layout
+    auto store_row = [&](int s_row, const f32x4 xlo, const f32x4 xhi) {
+#if defined(OFX_X_TINYSTORE) // timing experiment: every row lands in the first MB of the flow (L2 hits, no HBM write stream)
+        const int fso = __builtin_amdgcn_readfirstlane((fso0 + (s_row - PR) * fstep) & 0xff000);
+#else
+        const int fso = __builtin_amdgcn_readfirstlane(fso0 + (s_row - PR) * fstep); // this row's offset in the flow
+#endif
+        // two gap-free streaming stores of 1 KB; the lanes past the tile's end are dropped by the resource's range check
+#if defined(OFX_X_NOSTORE) // timing experiment: the row is exchanged but never stored
+        asm volatile("" : : "v"(xlo), "v"(xhi), "s"(fso));
+#else
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xlo), rs_flow, vo_lo, fso, OFX_LK_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xhi), rs_flow, vo_hi, fso, OFX_LK_STORE_AUX);
+#endif
+        if (__builtin_expect(ragged, 0)) { // the one lane whose chunk holds a single pixel
+            const u32x4 ql = __builtin_bit_cast(u32x4, xlo), qh = __builtin_bit_cast(u32x4, xhi);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{ql.x, ql.y}, rs_flow, st_lo2 ? l16 : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{qh.x, qh.y}, rs_flow, st_hi2 ? l16 + 1024u : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
+        }
+    };
+    // OFX_LK_DEFER_STORE: the row of step s_row out of its exchange row (s_row & 1), and its stores
+    [[maybe_unused]] auto deferred_store = [&](int s_row) {
+        const lds_ptr xl_r = xl_base + (s_row & 1) * kLkWaveLds + lane_off_var(l16);
+        const f32x4 dlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
+        const f32x4 dhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
+        store_row(s_row, dlo, dhi);
+    };
+
     auto body = [&](auto K, int s) {
         constexpr int k = decltype(K)::value; // s mod 3
         const int yy = y_lo0 + s;             // derivative row entering the window (low halves)
@@ -362,6 +402,9 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         s2 ix[4], iy[4], it[4];
         derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
         accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
+        if constexpr (DEFER) {
+            if (s > PR) deferred_store(s - 1); // the row the step before exchanged: this step's row loads are already on their way
+        }
         auto take_rows = [&]() {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (DMA) {
@@ -432,33 +475,20 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 const float fu[4] = {uv[0], uv[2], uv[4], uv[6]}, fv[4] = {uv[1], uv[3], uv[5], uv[7]};
                 warp_row_prepare<ROWWIN>(rs_wsrc, A.warp_scale, A.w, A.h, A.pitch, A.row0, A.row_end, cb, yw, wnpx, fu, fv, WM, wmiss);
             }
-            *(__attribute__((address_space(3))) f32x4 *)(xl_w) = f32x4{uv[0], uv[1], uv[2], uv[3]};
-            *(__attribute__((address_space(3))) f32x4 *)(xl_w + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
+            const lds_ptr xl_ws = DEFER ? xl_w + (s & 1) * kLkWaveLds : xl_w;
+            *(__attribute__((address_space(3))) f32x4 *)(xl_ws) = f32x4{uv[0], uv[1], uv[2], uv[3]};
+            *(__attribute__((address_space(3))) f32x4 *)(xl_ws + 16) = f32x4{uv[4], uv[5], uv[6], uv[7]};
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const lds_ptr xl_r = xl_base + lane_off_var(l16);
-            xlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
-            xhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
+            if constexpr (!DEFER) {
+                const lds_ptr xl_r = xl_base + lane_off_var(l16);
+                xlo = *(__attribute__((address_space(3))) f32x4 *)(xl_r);
+                xhi = *(__attribute__((address_space(3))) f32x4 *)(xl_r + 1024);
+            }
         }
         take_rows();
-        if (emit) {
-#if defined(OFX_X_TINYSTORE) // timing experiment: every row lands in the first MB of the flow (L2 hits, no HBM write stream)
-            const int fso = __builtin_amdgcn_readfirstlane((fso0 + (s - PR) * fstep) & 0xff000);
-#else
-            const int fso = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep); // this row's offset in the flow
-#endif
-            // two gap-free streaming stores of 1 KB; the lanes past the tile's end are dropped by the resource's range check
-#if defined(OFX_X_NOSTORE) // timing experiment: the row is exchanged but never stored
-            asm volatile("" : : "v"(xlo), "v"(xhi), "s"(fso));
-#else
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xlo), rs_flow, vo_lo, fso, OFX_LK_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xhi), rs_flow, vo_hi, fso, OFX_LK_STORE_AUX);
-#endif
-            if (__builtin_expect(ragged, 0)) { // the one lane whose chunk holds a single pixel
-                const u32x4 ql = __builtin_bit_cast(u32x4, xlo), qh = __builtin_bit_cast(u32x4, xhi);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{ql.x, ql.y}, rs_flow, st_lo2 ? l16 : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{qh.x, qh.y}, rs_flow, st_hi2 ? l16 + 1024u : (uint32_t)kOob, fso, OFX_LK_STORE_AUX);
-            }
+        if constexpr (!DEFER) {
+            if (emit) store_row(s, xlo, xhi);
         }
     };
 
@@ -485,6 +515,9 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         OFX_LK_PRIO_STEP();
     }
 #undef OFX_LK_PRIO_STEP
+    if constexpr (DEFER) {
+        if (nsteps > PR) deferred_store(nsteps - 1); // the last row
+    }
     // the rows issued by the last step are never taken: they must have landed before the wave gives its LDS back
     if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if constexpr (WOUT) { // the warped row of the last step

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 template <int R, int MODE, bool FAST, int ITER, bool DMA = false, int NC = 4>
 __global__ __launch_bounds__(64, NC == 8 ? OFX_WIDE_ITER_MIN_WAVES : OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t xlds[NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLds)];
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLdsX)];
     const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
     if constexpr (NC == 8) {
         static_assert(!DMA, "the wide march has no deep fetch");
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, NC == 8 ? (WOUT ? 2 : OFX_WIDE_MIN_BLOCKS) : (
         }
     } else if (b < S.first[0]) {
         if constexpr (NC == 8) lk_wave_w<R, MODE, FAST, WOUT, 8>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * kLkWaveLdsW);
-        else lk_wave<R, MODE, false, false, FAST, DMA, WOUT>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLds));
+        else lk_wave<R, MODE, false, false, FAST, DMA, WOUT>(S.lk, 4 * (b - OFX_STREAM_MAX_BATCH) + wv, tid & 63, lds + wv * (DMA ? kLkWaveLdsDma : kLkWaveLdsX));
     } else {
         int i = 0;
         while (i + 1 < kPyrStages && b >= S.first[i + 1]) ++i;
@@ -319,7 +319,7 @@ int launch_iter_r(const LkLevelIn *lv, int n, hipStream_t st)
 template <int R, int MODE, bool FAST, bool DMA, int WOUT, int NC = 4>
 int launch_stream_rd(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st)
 {
-    constexpr size_t wave_lds = NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLds);
+    constexpr size_t wave_lds = NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLdsX);
     // Next to the staging blocks the LK stage does best with 2 waves per SIMD when the tick carries one pair and 4 when it
     // carries more (measured, 4K: one pair 58.2 / 59.8 us per frame at 2 / 3; two pairs 59.7 / 57.2 / 56.5 at 2 / 3 / 4)
     // (eight columns per lane: a wave carries twice the pixels, and three blocks fit a CU: 1 / 2 waves per SIMD)

@@ -691,9 +691,22 @@ extern "C" int ofx_conv_3ch_1ch_f32(const uint8_t *d_src3, int w, int h, float *
     return OFX_OK;
 }
 
+// srm_march.hip: the same sums on the march (sliding integer windows / products formed once); OFX_E_UNSUPPORTED = not their shape
+int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int ww, int wh, int32_t *d_dst, hipStream_t st);
+int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, hipStream_t st);
+static bool srm_march_on()
+{
+    static const bool on = [] { const char *e = getenv("OFX_SRM_MARCH"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 extern "C" int ofx_srm_u8(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int ww, int wh, int32_t *d_dst, void *stream)
 {
     OFX_REQUIRE(d_a && d_b && d_dst && w > 0 && h > 0 && ww > 0 && wh > 0, "ofx_srm_u8: bad arguments");
+    if (srm_march_on()) {
+        const int rc = ofx_srm_u8_march(d_a, d_b, w, h, ww, wh, d_dst, ofx_stream(stream));
+        if (rc != OFX_E_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL((srm_kernel<uint8_t, int32_t>), grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_a, d_b, w, h, ww, wh, d_dst);
     OFX_HIP(hipGetLastError());
     return OFX_OK;
@@ -702,6 +715,10 @@ extern "C" int ofx_srm_u8(const uint8_t *d_a, const uint8_t *d_b, int w, int h, 
 extern "C" int ofx_srm_f32(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, void *stream)
 {
     OFX_REQUIRE(d_a && d_b && d_dst && w > 0 && h > 0 && ww > 0 && wh > 0, "ofx_srm_f32: bad arguments");
+    if (srm_march_on()) {
+        const int rc = ofx_srm_f32_march(d_a, d_b, w, h, ww, wh, d_dst, ofx_stream(stream));
+        if (rc != OFX_E_UNSUPPORTED) return rc;
+    }
     hipLaunchKernelGGL((srm_kernel<float, float>), grid2d(w, h), dim3(256), 0, ofx_stream(stream), d_a, d_b, w, h, ww, wh, d_dst);
     OFX_HIP(hipGetLastError());
     return OFX_OK;

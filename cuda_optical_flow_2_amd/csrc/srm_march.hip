@@ -1,0 +1,336 @@
+// gpu::srm_1ch / cpu::srm_1ch as a MARCH (round 4): dst(y, x) = sum over the ww x wh window around (y, x), clipped
+// at the image border, of a * b (OptFlowGpu.cu:1463-1502, OptFlowCPU.cpp:162-200).  The stand-alone entry point used to be the
+// reference's own shape -- one thread per pixel, ww * wh taps each, 2 * ww * wh byte loads per pixel: 317 us per 4K plane at 9x9, 0.02
+// of the HBM roofline on its 6 B/px.  Integer sums are exact and do not depend on the order of their terms (int32 wraps like the
+// reference's int accumulator), so the window slides:
+//   * a wave walks down a strip of rows of a 256-column tile, a lane owns 4 adjacent columns; per step it fetches the row entering
+//     the vertical window and the row leaving it (one dword of each plane per lane, a step ahead) and updates four running sums
+//     V[c] += a_in * b_in - a_out * b_out (byte products by SDWA multiplies);
+//   * the horizontal window goes through the wave's private LDS row: every lane writes its four V, reads the ww + 3 values its four
+//     outputs cover and slides -- out0 = the first ww, out1 = out0 - v[0] + v[ww], ... -- in plain 32-bit adds;
+//   * one 16-byte store per lane and row: 1 KB per wave, gap-free.
+// Algorithmic bytes per call: 2 u8 read + one int32 written = 6 B/px; five calls per level = 30.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "ofx.h"
+#include "ofx_internal.h"
+
+namespace {
+
+constexpr int kSrmPad = 64;                           // ints behind a wave's LDS row: the reads of the lanes past the tile's last output
+constexpr int kSrmWaveInts = 256 + kSrmPad;
+constexpr int kSrmOob = (int)0x80000000;
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t srm_rsrc(const void *base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00027000);
+}
+
+// byte j of x times byte j of y
+template <int J>
+__device__ __forceinline__ int mul_byte(uint32_t x, uint32_t y)
+{
+    return (int)(((x >> (8 * J)) & 0xffu) * ((y >> (8 * J)) & 0xffu)); // (selects as v_mul_u32_u24_sdwa BYTE_J x BYTE_J)
+}
+
+struct SrmArgs {
+    const uint8_t *a, *b;
+    int32_t *dst;
+    int w, h, ww, wh;
+    int tiles_x, strips, strip_h, out_w; // out_w: output columns of a tile (a multiple of 4)
+};
+
+// WW > 0: the horizontal window's width at compile time (its loop unrolled); 0: A.ww at run time
+template <int WW>
+__global__ __launch_bounds__(256) void srm_u8_march_kernel(const SrmArgs A)
+{
+    __shared__ __attribute__((aligned(16))) int lds[4 * kSrmWaveInts];
+    const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int item = (int)blockIdx.x * 4 + wv;
+    if (item >= A.tiles_x * A.strips) return;
+    const int tile = item % A.tiles_x, strip = item / A.tiles_x;
+    const int ww = WW > 0 ? WW : A.ww, wh = A.wh, w = A.w, h = A.h;
+    const int ox = ww >> 1, oy = wh >> 1, ry = wh - 1 - oy;
+    const int x0 = tile * A.out_w - ox; // image column of the wave's LDS index 0
+    const int cb = x0 + 4 * lane;       // this lane's first column
+    const int ys = strip * A.strip_h, ye = min(ys + A.strip_h, h);
+    int *row = lds + wv * kSrmWaveInts;
+    if (lane < kSrmPad / 4) *(int4 *)(row + 256 + 4 * lane) = int4{0, 0, 0, 0};
+
+    const __amdgpu_buffer_rsrc_t ra = srm_rsrc(A.a, (unsigned)w * (unsigned)h), rb = srm_rsrc(A.b, (unsigned)w * (unsigned)h);
+    const __amdgpu_buffer_rsrc_t rd = srm_rsrc(A.dst, (unsigned)w * (unsigned)h * 4u);
+    // The planes are tightly packed (w bytes per row, any w >= 4): the dword is fetched from a base column clamped into the row and
+    // its bytes put in place by a per-lane selector, zero where the column lies outside the image.
+    const int cbl = min(max(cb, 0), w - 4);
+    uint32_t sel = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = cb + j;
+        const uint32_t sj = (x >= 0 && x < w && x - cbl >= 0 && x - cbl < 4) ? (uint32_t)(x - cbl) : 0x0cu;
+        sel |= sj << (8 * j);
+    }
+    const uint32_t voff = (uint32_t)cbl;
+    auto row_off = [&](int y) -> int { return (uint32_t)y < (uint32_t)h ? y * w : kSrmOob; };
+    auto fetch = [&](int y, uint32_t &pa, uint32_t &pb) {
+        const int o = row_off(y);
+        pa = __builtin_amdgcn_raw_buffer_load_b32(ra, voff, o, 0);
+        pb = __builtin_amdgcn_raw_buffer_load_b32(rb, voff, o, 0);
+    };
+    auto place = [&](uint32_t raw) -> uint32_t { return __builtin_amdgcn_perm(0u, raw, sel); };
+
+    int V[4] = {0, 0, 0, 0};
+    auto add_row = [&](uint32_t pa, uint32_t pb) {
+        const uint32_t xa = place(pa), xb = place(pb);
+        V[0] += mul_byte<0>(xa, xb);
+        V[1] += mul_byte<1>(xa, xb);
+        V[2] += mul_byte<2>(xa, xb);
+        V[3] += mul_byte<3>(xa, xb);
+    };
+    auto sub_row = [&](uint32_t pa, uint32_t pb) {
+        const uint32_t xa = place(pa), xb = place(pb);
+        V[0] -= mul_byte<0>(xa, xb);
+        V[1] -= mul_byte<1>(xa, xb);
+        V[2] -= mul_byte<2>(xa, xb);
+        V[3] -= mul_byte<3>(xa, xb);
+    };
+    // priming: rows ys - oy .. ys + ry - 1 (rows outside the image read as zeros)
+    for (int y = ys - oy; y < ys + ry; ++y) {
+        uint32_t pa, pb;
+        fetch(y, pa, pb);
+        add_row(pa, pb);
+    }
+    // the store: outputs x0 + ox + 4 lane + j, j < nval
+    const int xo = x0 + ox + 4 * lane;
+    const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
+    const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
+    const bool ragged = __any(nval > 0 && nval < 4) != 0;
+    uint32_t ia, ib, oa, ob;
+    fetch(ys + ry, ia, ib);
+    fetch(ys - oy, oa, ob);
+    for (int y = ys; y < ye; ++y) {
+        uint32_t nia, nib, noa, nob; // the rows of the next step
+        fetch(y + 1 + ry, nia, nib);
+        fetch(y + 1 - oy, noa, nob);
+        add_row(ia, ib); // V = the vertical window of row y
+        *(int4 *)(row + 4 * lane) = int4{V[0], V[1], V[2], V[3]};
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int *src = row + 4 * lane; // this lane's four windows start at LDS indices 4 lane + j
+        int acc = 0;
+        if constexpr (WW > 0) {
+#pragma unroll
+            for (int k = 0; k < WW; ++k) acc += src[k];
+        } else {
+            for (int k = 0; k < ww; ++k) acc += src[k];
+        }
+        const int o0 = acc;
+        const int o1 = o0 - src[0] + src[ww];
+        const int o2 = o1 - src[1] + src[ww + 1];
+        const int o3 = o2 - src[2] + src[ww + 2];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // (the next step's write must not overtake these reads: in order within a wave anyway)
+        const int so = __builtin_amdgcn_readfirstlane(y * w * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)o3}, rd, st_off, so, 2 /* nt */);
+        if (__builtin_expect(ragged, 0)) { // the lane at the image's right edge: one to three pixels
+            const int ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)ov[j], rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
+        }
+        sub_row(oa, ob); // row y - oy leaves
+        ia = nia, ib = nib, oa = noa, ob = nob;
+    }
+}
+
+// ---- gpu::srm_1ch_float (OptFlowGpu.cu:1549-1588): float planes, a float accumulator fed in ROW-MAJOR tap order -----------------------
+// The order is part of the result (float addition does not associate; sums beyond 2^24 are the rule: SURVEY 8a row 8), so nothing
+// slides here: every output still adds its ww * wh products one after the other, top row first, left to right -- but the products are
+// formed ONCE per pixel (the plain kernel forms each of them ww * wh times and fetches 2 * ww * wh floats per output from global
+// memory).  A wave walks down a strip of a 256-column tile; the products of the newest image row go into slot (row mod wh) of a ring
+// of wh rows in the wave's LDS; a lane then accumulates its four adjacent outputs: per window row it reads the ww + 3 products they
+// cover and feeds four independent accumulators in tap order (plain v_add_f32: the cheap issue class).  A tap outside the image is
+// skipped by the reference; here it adds the +0.0f stored for it, which leaves a float accumulator that started at +0.0f unchanged
+// bit for bit (it can never be -0.0f).  12 B/px per call (2 floats read, one written).
+struct SrmFArgs {
+    const float *a, *b;
+    float *dst;
+    int w, h, ww, wh;
+    int tiles_x, strips, strip_h, out_w;
+};
+
+constexpr int kSrmFRow = 256 + 64; // floats per ring row (the reads of the lanes past the tile's last output land in the pad)
+
+// (one wave per block: the ring of a 19x19 window is 24 KB, and a block's LDS is what limits how many waves a CU holds)
+template <int WW>
+__global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float ring_all[]; // wh rows x kSrmFRow
+    const int lane = (int)threadIdx.x, wv = 0;
+    const int item = (int)blockIdx.x;
+    if (item >= A.tiles_x * A.strips) return;
+    const int tile = item % A.tiles_x, strip = item / A.tiles_x;
+    const int ww = WW > 0 ? WW : A.ww, wh = A.wh, w = A.w, h = A.h;
+    const int ox = ww >> 1, oy = wh >> 1, ry = wh - 1 - oy;
+    const int x0 = tile * A.out_w - ox;
+    const int cb = x0 + 4 * lane;
+    const int ys = strip * A.strip_h, ye = min(ys + A.strip_h, h);
+    float *ring = ring_all + (size_t)wv * (size_t)wh * kSrmFRow;
+    for (int r = 0; r < wh; ++r)
+        if (lane < 16) *(float4 *)(ring + r * kSrmFRow + 256 + 4 * lane) = float4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const __amdgpu_buffer_rsrc_t ra = srm_rsrc(A.a, (unsigned)w * (unsigned)h * 4u), rb = srm_rsrc(A.b, (unsigned)w * (unsigned)h * 4u);
+    const __amdgpu_buffer_rsrc_t rd = srm_rsrc(A.dst, (unsigned)w * (unsigned)h * 4u);
+    // per column: its byte offset in a row, or the out-of-range marker (reads 0) where the column lies outside the image
+    uint32_t co[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) co[j] = (cb + j >= 0 && cb + j < w) ? (uint32_t)(cb + j) * 4u : (uint32_t)kSrmOob;
+    const bool whole = cb >= 0 && cb + 4 <= w; // (one 16-byte load instead of four)
+    auto row_off = [&](int y) -> int { return (uint32_t)y < (uint32_t)h ? y * w * 4 : kSrmOob; };
+    auto fetch = [&](const __amdgpu_buffer_rsrc_t &rs, int y) -> float4 {
+        const int o = row_off(y);
+        if (whole) return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, co[0], o, 0));
+        float4 v;
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, co[0], o, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, co[1], o, 0));
+        v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, co[2], o, 0));
+        v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, co[3], o, 0));
+        return v;
+    };
+    // products of image row y into its ring slot; rows and columns outside the image give +0.0f (0 * 0)
+    auto put_row = [&](int y, const float4 pa, const float4 pb) {
+        int slot = y % wh;
+        if (slot < 0) slot += wh;
+        const bool in_img = (uint32_t)y < (uint32_t)h;
+        float4 p{pa.x * pb.x, pa.y * pb.y, pa.z * pb.z, pa.w * pb.w};
+        if (!in_img) p = float4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (co[j] == (uint32_t)kSrmOob) (&p.x)[j] = 0.0f; // (a NaN / Inf next to the border must not leak into a skipped tap)
+        *(float4 *)(ring + slot * kSrmFRow + 4 * lane) = p;
+    };
+    for (int y = ys - oy; y < ys + ry; ++y) put_row(y, fetch(ra, y), fetch(rb, y));
+    const int xo = x0 + ox + 4 * lane;
+    const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
+    const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
+    const bool ragged = __any(nval > 0 && nval < 4) != 0;
+    float4 na = fetch(ra, ys + ry), nb = fetch(rb, ys + ry);
+    for (int y = ys; y < ye; ++y) {
+        const float4 ca = na, cb4 = nb;
+        na = fetch(ra, y + 1 + ry), nb = fetch(rb, y + 1 + ry); // the next step's row, a step ahead
+        put_row(y + ry, ca, cb4);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+        int slot = (y - oy) % wh;
+        if (slot < 0) slot += wh;
+        for (int p = 0; p < wh; ++p) { // window rows top to bottom
+            const float *src = ring + slot * kSrmFRow + 4 * lane;
+            if constexpr (WW > 0) {
+                float t[WW + 3];
+#pragma unroll
+                for (int k = 0; k < (WW + 3 + 3) / 4; ++k) {
+                    const float4 q = *(const float4 *)(src + 4 * k);
+                    if (4 * k + 0 < WW + 3) t[4 * k + 0] = q.x;
+                    if (4 * k + 1 < WW + 3) t[4 * k + 1] = q.y;
+                    if (4 * k + 2 < WW + 3) t[4 * k + 2] = q.z;
+                    if (4 * k + 3 < WW + 3) t[4 * k + 3] = q.w;
+                }
+#pragma unroll
+                for (int q = 0; q < WW; ++q) { // taps left to right, four outputs side by side
+                    acc0 += t[q];
+                    acc1 += t[q + 1];
+                    acc2 += t[q + 2];
+                    acc3 += t[q + 3];
+                }
+            } else {
+                for (int q = 0; q < ww; ++q) {
+                    acc0 += src[q];
+                    acc1 += src[q + 1];
+                    acc2 += src[q + 2];
+                    acc3 += src[q + 3];
+                }
+            }
+            slot = slot + 1 == wh ? 0 : slot + 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int so = __builtin_amdgcn_readfirstlane(y * w * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, acc0), __builtin_bit_cast(uint32_t, acc1), __builtin_bit_cast(uint32_t, acc2),
+                                                       __builtin_bit_cast(uint32_t, acc3)}, rd, st_off, so, 2 /* nt */);
+        if (__builtin_expect(ragged, 0)) {
+            const float ov[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ov[j]), rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
+        }
+    }
+}
+
+int env_pos(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
+
+} // namespace
+
+// returns OFX_E_UNSUPPORTED when the shape is not one the march handles (the caller keeps the plain kernel for those)
+int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int ww, int wh, int32_t *d_dst, hipStream_t st)
+{
+    if (w < 8 || ww < 1 || wh < 1 || ww > 57 || (long long)w * h * 4 >= (1ll << 32) || (long long)w * h >= (1ll << 31)) return OFX_E_UNSUPPORTED;
+    SrmArgs A{};
+    A.a = d_a, A.b = d_b, A.dst = d_dst, A.w = w, A.h = h, A.ww = ww, A.wh = wh;
+    A.out_w = (256 - (ww - 1)) & ~3;
+    A.tiles_x = ofx_div_up(w, A.out_w);
+    // strips: enough waves to fill the chip several times over (the kernel is latency-bound per wave), but long enough that the
+    // wh - 1 priming rows stay a minor cost
+    static const int target = env_pos("OFX_SRM_WAVES", 256 * 4 * 8);
+    int strips = target / A.tiles_x;
+    if (strips < 1) strips = 1;
+    int strip_h = ofx_div_up(h, strips);
+    const int min_h = 4 * wh > 32 ? 4 * wh : 32;
+    if (strip_h < min_h) strip_h = min_h;
+    A.strip_h = strip_h;
+    A.strips = ofx_div_up(h, strip_h);
+    const int blocks = ofx_div_up(A.tiles_x * A.strips, 4);
+    switch (ww) {
+#define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL(srm_u8_march_kernel<N>, dim3((unsigned)blocks), dim3(256), 0, st, A); break;
+        OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
+        OFX_SRM_CASE(19) OFX_SRM_CASE(21) OFX_SRM_CASE(23)
+#undef OFX_SRM_CASE
+    default: hipLaunchKernelGGL(srm_u8_march_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, A); break;
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
+int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, hipStream_t st)
+{
+    if (w < 8 || ww < 1 || wh < 1 || ww > 57 || wh > 48 || (long long)w * h * 4 >= (1ll << 31)) return OFX_E_UNSUPPORTED;
+    SrmFArgs A{};
+    A.a = d_a, A.b = d_b, A.dst = d_dst, A.w = w, A.h = h, A.ww = ww, A.wh = wh;
+    A.out_w = (256 - (ww - 1)) & ~3;
+    A.tiles_x = ofx_div_up(w, A.out_w);
+    static const int target = env_pos("OFX_SRM_WAVES", 256 * 4 * 8);
+    int strips = target / A.tiles_x;
+    if (strips < 1) strips = 1;
+    int strip_h = ofx_div_up(h, strips);
+    const int min_h = 4 * wh > 32 ? 4 * wh : 32;
+    if (strip_h < min_h) strip_h = min_h;
+    A.strip_h = strip_h;
+    A.strips = ofx_div_up(h, strip_h);
+    const int blocks = A.tiles_x * A.strips;
+    const size_t lds = (size_t)wh * kSrmFRow * sizeof(float);
+    switch (ww) {
+#define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL(srm_f32_march_kernel<N>, dim3((unsigned)blocks), dim3(64), lds, st, A); break;
+        OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
+        OFX_SRM_CASE(19) OFX_SRM_CASE(21) OFX_SRM_CASE(23)
+#undef OFX_SRM_CASE
+    default: hipLaunchKernelGGL(srm_f32_march_kernel<0>, dim3((unsigned)blocks), dim3(64), lds, st, A); break;
+    }
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}

@@ -1054,6 +1054,26 @@ def test_gpu_namespace_primitives_golden(gpu, golden):
             assert_same(gpu.srm_1ch(g["a"], g["b"], ww, wh, variant), g[f"srm_{ww}x{wh}"], f"gpu::{variant} {ww}x{wh}")
 
 
+@pytest.mark.parametrize("shape", [(41, 33), (259, 70), (520, 97), (1000, 41), (8, 9), (255, 64), (257, 40)])
+def test_window_sums_on_the_march_equal_the_oracle(gpu, oracle, shape):
+    """gpu::srm_1ch / gpu::srm_1ch_float run as marches since round 4 (csrc/srm_march.hip: sliding integer windows through a wave's
+    LDS row; float products formed once and added in the reference's row-major tap order): every window shape the entry points
+    take -- odd, even, wider than high, a window larger than the image -- on widths around the 256-column tile and the 248 / 250
+    output columns of a tile, odd widths (unaligned rows, a ragged last store), uniform-random bytes (sums far beyond 2^24) and
+    floats with NaN / Inf next to the border: int32 bit for bit, float bit for bit against the restatement of OptFlowGpu.cu:1549-1588."""
+    w, h = shape
+    rng = np.random.default_rng(w * 1000 + h)
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    b = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    fa = (rng.normal(size=(h, w)) * 300).astype(np.float32)
+    fb = (rng.normal(size=(h, w)) * 300).astype(np.float32)
+    fa[0, 0], fa[h - 1, w - 1], fb[h // 2, 0], fa[h // 2, w - 1] = np.nan, np.inf, -np.inf, -0.0
+    for ww, wh in ((9, 9), (19, 19), (3, 3), (5, 9), (4, 6), (23, 7), (2, 2), (1, 1), (15, 15), (31, 3), (7, 25)):
+        assert_same(gpu.srm_1ch(a, b, ww, wh), oracle.srm_1ch(a, b, ww, wh), f"gpu::srm_1ch {w}x{h} {ww}x{wh}")
+    for ww, wh in ((19, 19), (9, 9), (3, 7), (4, 6), (1, 1), (23, 5), (10, 3)):
+        assert_same(gpu.srm_1ch_float(fa, fb, ww, wh), oracle.srm_1ch_f32(fa, fb, ww, wh), f"gpu::srm_1ch_float {w}x{h} {ww}x{wh}")
+
+
 def test_gpu_namespace_float_primitives(gpu, oracle):
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
