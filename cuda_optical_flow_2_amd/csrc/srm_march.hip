@@ -291,7 +291,8 @@ int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int w
     int strips = target / A.tiles_x;
     if (strips < 1) strips = 1;
     int strip_h = ofx_div_up(h, strips);
-    const int min_h = 4 * wh > 32 ? 4 * wh : 32;
+    static const int min_strip = env_pos("OFX_SRM_MIN_STRIP", 0);
+    const int min_h = min_strip ? min_strip : 16; // (measured at 4K: 9x9 14.6 / 13.4 / 16.4 us, 19x19 19.5 / 19.4 / 24.4 us with strips of 8 / 16 / 32 rows)
     if (strip_h < min_h) strip_h = min_h;
     A.strip_h = strip_h;
     A.strips = ofx_div_up(h, strip_h);
@@ -318,7 +319,10 @@ int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, 
     int strips = target / A.tiles_x;
     if (strips < 1) strips = 1;
     int strip_h = ofx_div_up(h, strips);
-    const int min_h = 4 * wh > 32 ? 4 * wh : 32;
+    // (priming a strip costs products only -- no accumulation --, and the accumulation is what the kernel spends its time on: short
+    // strips, several waves per SIMD)
+    static const int min_strip = env_pos("OFX_SRMF_MIN_STRIP", 0);
+    const int min_h = min_strip ? min_strip : 8;
     if (strip_h < min_h) strip_h = min_h;
     A.strip_h = strip_h;
     A.strips = ofx_div_up(h, strip_h);
