@@ -56,10 +56,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 // of LDS and is stored one step later, in the middle of the next step -- after that step's row loads have been issued, so that no
 // load queues behind the two 1 KB stores of the row before it.  Measured: profiles/r04_ablation.txt.
 // 0: never; 1: every launch of the buffer march; 2 (shipped): the accumulating launches of lk_iter only (ITER 1, 2, 4), whose step
-// holds the most memory operations (row loads, the old flow, eight warp taps, three stores): +2.3 % at 4K / 5 iterations; the
-// reference-defined tick measured 0 % (ring in the Infinity Cache) to -3 % (frames from HBM) with it and keeps the plain order.
+// holds the most memory operations (row loads, the old flow, eight warp taps, three stores): between +2.3 % and 0 at 4K / 5
+// iterations (two batches, different boxes); the reference-defined tick measured 0 % (ring in the Infinity Cache) to -3 % (frames
+// from HBM) with it and keeps the plain order.
 #ifndef OFX_LK_DEFER_STORE
 #define OFX_LK_DEFER_STORE 2
+#endif
+#ifndef OFX_LK_ACC_LOAD_AUX
+#define OFX_LK_ACC_LOAD_AUX 0
 #endif
 constexpr int kLkXRows = OFX_LK_DEFER_STORE ? 2 : 1;            // exchange rows per wave
 constexpr int kLkWaveLdsX = kLkXRows * kLkWaveLds;              // what a wave of the buffer march owns without the deep fetch
@@ -380,13 +384,15 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             asm("" : "=v"(old_a), "=v"(old_b));
             if (emit) {
                 const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
+                // (OFX_LK_ACC_LOAD_AUX: cache-policy bits of the old flow's loads.  2 = nt -- "read once, do not displace the image rows the
+                // trailing window re-reads" -- measured 20 % SLOWER at 4K / 5 iterations: 554 vs 457 us, profiles/r04_ablation.txt batch 4)
                 if constexpr (INTERIOR) {
-                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off, fnat, 0));
-                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off + 16u, fnat, 0));
+                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off, fnat, OFX_LK_ACC_LOAD_AUX));
+                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off + 16u, fnat, OFX_LK_ACC_LOAD_AUX));
                 } else { // (per pixel: a level of odd width ends inside a 16-byte piece)
                     auto off = [&](int j) { return cm[j] ? nat_off + 8u * (uint32_t)j : (uint32_t)kOob; };
-                    const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(0), fnat, 0), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(1), fnat, 0);
-                    const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(2), fnat, 0), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(3), fnat, 0);
+                    const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(0), fnat, OFX_LK_ACC_LOAD_AUX), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(1), fnat, OFX_LK_ACC_LOAD_AUX);
+                    const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(2), fnat, OFX_LK_ACC_LOAD_AUX), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(3), fnat, OFX_LK_ACC_LOAD_AUX);
                     old_a = __builtin_bit_cast(f32x4, u32x4{p0.x, p0.y, p1.x, p1.y});
                     old_b = __builtin_bit_cast(f32x4, u32x4{p2.x, p2.y, p3.x, p3.y});
                 }

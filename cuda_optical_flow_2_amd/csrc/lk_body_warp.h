@@ -20,14 +20,28 @@ namespace ofx_dev {
 
 struct WarpRowState {      // a row of a lane between the two stages
     float fx[4], fy[4];    // the fractions of the source coordinates
-    uint32_t sel[4];       // per pixel the byte selector (xi - xb, x1 - xb, zero, zero) into its two dwords
+    uint32_t sel[4];       // per pixel the byte selector (xi - xb, x1 - xb, zero, zero) into its two dwords (general rows only)
     uint32_t ra[4], rb[4]; // per pixel the dwords of rows yi and y1 (loads in flight between the stages)
+    int general;           // wave-uniform: some pixel of the wave's row has its taps at the right end of a source row (see below)
 };
+
+// Round 4: the common row.  The selector only differs from (byte 0, byte 1) where a tap column reaches the last three bytes of the
+// row pitch or the image's last column -- for every other pixel the dword fetched AT byte xi holds p(xi) in byte 0 and p(xi + 1) in
+// byte 1.  One test per lane-row (the largest of the four xi against min(pitch - 4, w - 2)) and a wave-uniform branch replace the
+// seven selector instructions per pixel in stage 1 and the two v_perm per pixel in stage 2; v_cvt_f32_ubyte0 / 1 read the bytes where
+// they lie.  Same bytes (the iteration tests pass with either form).  MEASURED SLOWER and therefore OFF: 4K, 5 iterations, the
+// accumulating launch that also warps takes 498-517 us with it against 457-461 us without (profiles/r04_ablation.txt, batch 4) --
+// 38 fewer vector instructions per row step, but the tap loads now sit in two arms of a branch, and at the join hipcc's wait-count
+// insertion no longer lets them stay in flight across the step.  OFX_WARP_FAST_ROWS=1 builds it.
+#ifndef OFX_WARP_FAST_ROWS
+#define OFX_WARP_FAST_ROWS 0
+#endif
 
 __device__ __forceinline__ void warp_row_clear(WarpRowState &M)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.sel[k] = 0x0c0c0c0cu, M.ra[k] = M.rb[k] = 0u;
+    M.general = 1;
 }
 
 // Stage 1: source coordinates and selectors; issues the eight tap loads through `rs` (the rows [row0, row_end) of the warp source,
@@ -40,6 +54,7 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
 {
     const float xf0 = (float)x0, yf = (float)y, wmaxf = (float)(w - 1), hmaxf = (float)(h - 1);
     const int wmax = w - 1, hmax = h - 1;
+    int xi[4], ya[4], yb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float xr = xf0 + (float)k;
@@ -47,20 +62,34 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
         const bool ok = __builtin_fabsf(sxr) <= 1e9f && __builtin_fabsf(syr) <= 1e9f; // (NaN fails)
         const float sx = __builtin_amdgcn_fmed3f(ok ? sxr : xr, 0.0f, wmaxf);
         const float sy = __builtin_amdgcn_fmed3f(ok ? syr : yf, 0.0f, hmaxf);
-        const int xi = (int)sx, yi = (int)sy;
+        xi[k] = (int)sx;
+        const int yi = (int)sy;
         M.fx[k] = __builtin_amdgcn_fractf(sx); // == sx - (float)xi: sx >= 0, the difference is exact
         M.fy[k] = __builtin_amdgcn_fractf(sy);
-        const int xb = min(xi, pitch - 4); // the dword stays inside the row pitch
-        int ya = yi, yb = min(yi + 1, hmax);
+        ya[k] = yi, yb[k] = min(yi + 1, hmax);
         if constexpr (ROWWIN) {
-            if (k < npx && ok && (ya < row0 || yb >= row_end)) miss |= 1u << k;
-            ya = min(max(ya, row0), row_end - 1) - row0;
-            yb = min(max(yb, row0), row_end - 1) - row0;
+            if (k < npx && ok && (ya[k] < row0 || yb[k] >= row_end)) miss |= 1u << k;
+            ya[k] = min(max(ya[k], row0), row_end - 1) - row0;
+            yb[k] = min(max(yb[k], row0), row_end - 1) - row0;
         }
-        const uint32_t oa = (uint32_t)(ya * pitch + xb), ob = (uint32_t)(yb * pitch + xb);
-        M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, oa, 0, 0);
-        M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, ob, 0, 0);
-        M.sel[k] = (uint32_t)(xi - xb) | ((uint32_t)(min(xi + 1, wmax) - xb) << 8) | 0x0c0c0000u;
+    }
+    // the common row: every tap dword can be fetched at byte xi itself and holds p(xi), p(xi + 1) in its bytes 0 and 1
+    const int xlim = min(pitch - 4, w - 2);
+    M.general = !OFX_WARP_FAST_ROWS || __any(max(max(xi[0], xi[1]), max(xi[2], xi[3])) > xlim) != 0;
+    if (__builtin_expect(M.general, 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xb = min(xi[k], pitch - 4); // the dword stays inside the row pitch
+            M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(ya[k] * pitch + xb), 0, 0);
+            M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(yb[k] * pitch + xb), 0, 0);
+            M.sel[k] = (uint32_t)(xi[k] - xb) | ((uint32_t)(min(xi[k] + 1, wmax) - xb) << 8) | 0x0c0c0000u;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(ya[k] * pitch + xi[k]), 0, 0);
+            M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(yb[k] * pitch + xi[k]), 0, 0);
+        }
     }
 }
 
@@ -68,15 +97,20 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
 __device__ __forceinline__ uint32_t warp_row_finish(const WarpRowState &M)
 {
     uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t pa = __builtin_amdgcn_perm(0u, M.ra[k], M.sel[k]), pb = __builtin_amdgcn_perm(0u, M.rb[k], M.sel[k]);
-        const float p00 = (float)(pa & 0xffu), p01 = (float)((pa >> 8) & 0xffu);
+    auto blend = [&](int k, uint32_t pa, uint32_t pb) {
+        const float p00 = (float)(pa & 0xffu), p01 = (float)((pa >> 8) & 0xffu); // (v_cvt_f32_ubyte0 / 1)
         const float p10 = (float)(pb & 0xffu), p11 = (float)((pb >> 8) & 0xffu);
         const float a = p00 + M.fx[k] * (p01 - p00);
         const float b = p10 + M.fx[k] * (p11 - p10);
         const float v = a + M.fy[k] * (b - a);
         out |= ((uint32_t)(int)(v + 0.5f) & 0xffu) << (8 * k);
+    };
+    if (__builtin_expect(M.general, 0)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) blend(k, __builtin_amdgcn_perm(0u, M.ra[k], M.sel[k]), __builtin_amdgcn_perm(0u, M.rb[k], M.sel[k]));
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) blend(k, M.ra[k], M.rb[k]);
     }
     return out;
 }

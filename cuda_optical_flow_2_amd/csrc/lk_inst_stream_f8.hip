@@ -8,4 +8,6 @@ int stream_lk_float_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, co
     return launch_stream_mode_w8<OFX_MODE_LK_FLOAT, false>(radius, lv, n, S, stage_blocks, lds, st);
 }
 
+int levels_lk_float_w8(int radius, const LkLevelIn *lv, int n, hipStream_t st) { return launch_iter_mode_w8<OFX_MODE_LK_FLOAT, false, 0>(radius, lv, n, st); }
+
 } // namespace ofx_launch

@@ -507,4 +507,5 @@ int stream_compat_cpu(int radius, const LkLevelIn *lv, int n, StreamArgs &S, con
 // eight columns per lane (lk_body_wide.h)
 int stream_lk_float_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
 int stream_lk_float_fast_w8(int radius, const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_blocks, size_t lds, hipStream_t st);
+int levels_lk_float_w8(int radius, const LkLevelIn *lv, int n, hipStream_t st); // all levels of one pair (the pair-at-a-time path)
 } // namespace ofx_launch

@@ -138,6 +138,15 @@ int lk_dispatch(const ofx_lk_desc *d, int n, int window, int mode, int32_t *d_su
             return tab[mode == OFX_MODE_LK_FLOAT_FAST][iter - 1](radius, lv, m, st);
         }
     }
+    // (experiment, OFX_LK_PLAIN_COLS=8: the pair-at-a-time launch on the march with eight columns per lane)
+    static const bool plain_wide = [] { const char *e = getenv("OFX_LK_PLAIN_COLS"); return e && atoi(e) == 8; }();
+    if (plain_wide && !d_sums && mode == OFX_MODE_LK_FLOAT && !lv[0].a.accumulate && !lv[0].a.warp_out && radius >= 1 && radius <= 11) {
+        bool small = true;
+        for (int i = 0; i < m; ++i)
+            small = small && (size_t)(lv[i].a.row_end - lv[i].a.row0) * (size_t)lv[i].a.pitch < ((size_t)1 << 31) &&
+                    (size_t)(lv[i].a.out_y1 - lv[i].a.flow_row0) * (size_t)lv[i].a.w * 8 < ((size_t)1 << 31);
+        if (small) return ofx_launch::levels_lk_float_w8(radius, lv, m, st);
+    }
     if (d_sums) // the sums do not depend on the solve
         return mode != OFX_MODE_COMPAT_CPU ? ofx_launch::levels_lk_float(radius, lv, m, true, st) : ofx_launch::levels_compat_cpu(radius, lv, m, true, st);
     if (mode == OFX_MODE_LK_FLOAT_FAST) return ofx_launch::levels_lk_float_fast(radius, lv, m, st);

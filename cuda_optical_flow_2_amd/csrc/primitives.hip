@@ -273,7 +273,9 @@ __global__ __launch_bounds__(256) void bilateral_tiled_kernel(const uint8_t *src
 // v_exp_f32, two accumulations -- 6 VALU operations against the exact kernel's 7 doubles and a gather.  The float arithmetic
 // moves the quotient by ~1e-4 grey levels at most, so the truncated byte differs from the reference's by at most one where
 // the quotient lies that close to an integer (tests/test_gpu_surface.py asserts +-1 on every size and window of the exact
-// kernel's test).  Pixels outside the image are stored as a grey value of -4096: their weight underflows to exactly 0.
+// kernel's test).  Pixels outside the image are stored as a grey value of -1e6 (kBilFastOutside): d^2 = 1e12, so their weight
+// underflows to exactly 0 for every sigma_b the entry point lets through (<= 2e4: c * d^2 <= -1800; beyond, the exact kernel runs).
+constexpr float kBilFastOutside = -1.0e6f; // (exactly representable next to 0 .. 255: the differences stay exact)
 struct BilateralFastArg {
     float log2_spatial[kMaxBilateral * kMaxBilateral]; // log2 of the normalised spatial weights
     float c;                                           // -log2(e) / (2 sigma_b^2)
@@ -286,14 +288,14 @@ __global__ __launch_bounds__(256) void bilateral_fast_kernel(const uint8_t *src3
     constexpr int R = WW >> 1, TW = kBilTileW + 2 * R;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int ry = wh >> 1, rows = kBilTileH + 2 * ry;
-    float *gf = reinterpret_cast<float *>(smem);                                   // [rows][TW]: grey value (or -4096)
+    float *gf = reinterpret_cast<float *>(smem);                                   // [rows][TW]: grey value (or kBilFastOutside)
     uint32_t *spx = reinterpret_cast<uint32_t *>(gf + (size_t)rows * TW);           // [rows][TW]: s0 | s1 << 8 | s2 << 16
     const int tid = (int)threadIdx.x, x0 = (int)blockIdx.x * kBilTileW, y0 = (int)blockIdx.y * kBilTileH;
     int grey_src = 1; // every pixel of the tile: three equal channels that are the grey value itself (src == gray, main.cu:240)
     for (int i = tid; i < rows * TW; i += 256) {
         const int tx = x0 - R + i % TW, ty = y0 - ry + i / TW;
         uint32_t px = 0u;
-        float g = -4096.0f;
+        float g = kBilFastOutside;
         if (tx >= 0 && tx < w && ty >= 0 && ty < h) {
             const size_t q = 3 * ((size_t)ty * w + tx);
             const uint32_t s0 = src3[q], s1 = src3[q + 1], s2 = src3[q + 2], gq = gray3[q];
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void bilateral_fast_sep_kernel(const uint8_t *
     for (int i = tid; i < ROWS * TW; i += 256) {
         const int tx = x0 - R + i % TW, ty = y0 - R + i / TW;
         uint32_t px = 0u;
-        float g = -4096.0f;
+        float g = kBilFastOutside;
         if (tx >= 0 && tx < w && ty >= 0 && ty < h) {
             const size_t q = 3 * ((size_t)ty * w + tx);
             const uint32_t s0 = src3[q], s1 = src3[q + 1], s2 = src3[q + 2], gq = gray3[q];
@@ -764,6 +766,8 @@ extern "C" int ofx_bilateral_3ch_fast(const uint8_t *d_src3, const uint8_t *d_gr
     OFX_REQUIRE(d_src3 && d_gray3 && d_dst3 && w > 0 && h > 0, "ofx_bilateral_3ch_fast: bad arguments");
     OFX_REQUIRE(ww > 0 && wh > 0 && (ww & 1) && (wh & 1) && ww <= kMaxBilateral && wh <= ww && sigma_b > 0.0 && sigma_s > 0.0,
                 "ofx_bilateral_3ch_fast: window %dx%d unsupported (odd ww <= %d, odd wh <= ww)", ww, wh, kMaxBilateral);
+    // (with a very wide range Gaussian the sentinel of the out-of-image taps would no longer underflow to a zero weight)
+    if (sigma_b > 2.0e4) return ofx_bilateral_3ch(d_src3, d_gray3, d_dst3, w, h, ww, wh, sigma_s, sigma_b, stream);
     static thread_local BilateralFastArg B;
     double sp[kMaxBilateral * kMaxBilateral];
     ofx_generate_gaussian_kernel(sigma_s, ww, sp);

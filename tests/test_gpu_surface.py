@@ -210,7 +210,10 @@ def test_fast_bilateral_filter_is_within_one_lsb(gpu, cpu, oracle, golden, size)
     assert L.ofx_bilateral_wrappers_fast(1) == 0
     try:
         worst, differ = 0, 0
-        for (ww, wh, ss, sb) in ((9, 9, 2.0, 10.0), (5, 5, 1.5, 20.0), (7, 3, 1.0, 5.0), (13, 13, 3.0, 40.0)):
+        # (the last three: a range Gaussian so wide that a sentinel grey value of -4096 for the out-of-image taps no longer gave
+        # them a zero weight -- ADVICE r03: border pixels were pulled by whole grey levels; 5e4 falls back to the exact kernel)
+        for (ww, wh, ss, sb) in ((9, 9, 2.0, 10.0), (5, 5, 1.5, 20.0), (7, 3, 1.0, 5.0), (13, 13, 3.0, 40.0), (9, 9, 2.0, 400.0), (5, 5, 1.0, 3000.0),
+                                 (5, 5, 1.0, 5.0e4)):
             for src, gr, what in ((grey, grey, "grey"), (colour, grey, "colour"), (smooth, smooth, "smooth grey")):
                 got = gpu.bilinear_filter(src, gr, ww, wh, ss, sb).astype(np.int32)
                 want = oracle.bilateral_3ch(src, gr, ww, wh, ss, sb).astype(np.int32)
