@@ -65,6 +65,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 #ifndef OFX_LK_ACC_LOAD_AUX
 #define OFX_LK_ACC_LOAD_AUX 0
 #endif
+// 1: the accumulating launches read the old flow in the exchanged (gap-free) layout and put it back in place through LDS.  Built to
+// test whether the launch's fabric reads (FETCH_SIZE: 1.65 x its algorithmic reads) come from the two half-used 16-byte loads per
+// lane: they do not (FETCH_SIZE 811 vs 781 GiB-units, launch 452-455 vs 439-457 us: profiles/r04_ablation.txt batch 5).  Off.
+#ifndef OFX_LK_ACC_XLOAD
+#define OFX_LK_ACC_XLOAD 0
+#endif
 constexpr int kLkXRows = OFX_LK_DEFER_STORE ? 2 : 1;            // exchange rows per wave
 constexpr int kLkWaveLdsX = kLkXRows * kLkWaveLds;              // what a wave of the buffer march owns without the deep fetch
 constexpr int kLkDmaRowBytes = 256, kLkDmaRows = 6, kLkDmaSetBytes = kLkDmaRows * kLkDmaRowBytes;
@@ -386,7 +392,14 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
                 // (OFX_LK_ACC_LOAD_AUX: cache-policy bits of the old flow's loads.  2 = nt -- "read once, do not displace the image rows the
                 // trailing window re-reads" -- measured 20 % SLOWER at 4K / 5 iterations: 554 vs 457 us, profiles/r04_ablation.txt batch 4)
-                if constexpr (INTERIOR) {
+                if constexpr (INTERIOR && OFX_LK_ACC_XLOAD) {
+                    // the old flow in the EXCHANGED layout, as the stores write it: each of the two loads covers 1 KB without gaps
+                    // (in place, a lane's two 16-byte halves make every instruction touch all sixteen lines of the row and use half of
+                    // each).  Put back in place through the exchange row right before the add.
+                    const int fx = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep);
+                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, vo_lo, fx, OFX_LK_ACC_LOAD_AUX));
+                    old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, vo_hi, fx, OFX_LK_ACC_LOAD_AUX));
+                } else if constexpr (INTERIOR) {
                     old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off, fnat, OFX_LK_ACC_LOAD_AUX));
                     old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off + 16u, fnat, OFX_LK_ACC_LOAD_AUX));
                 } else { // (per pixel: a level of odd width ends inside a 16-byte piece)
@@ -467,6 +480,20 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #else
             solve_lane<MODE, FAST>(hxx, hyy, hxy, hxt, hyt, sopt, uv);
 #endif
+            if constexpr (ACC && INTERIOR && OFX_LK_ACC_XLOAD) {
+                // chunks l and l + 64 of the row -> this lane's own 32 bytes (the inverse of the exchange in front of the stores; the
+                // halo lanes, whose pixels are never stored, get whatever the row held).  A wave's LDS operations execute in order.
+                const lds_ptr xr = DEFER ? (lds_ptr)xlds + (s & 1) * kLkWaveLds : (lds_ptr)xlds;
+                const lds_ptr xq = xr + 32 * G::LO_LANE + lane_off_var(l16);
+                *(__attribute__((address_space(3))) f32x4 *)(xq) = old_a;
+                *(__attribute__((address_space(3))) f32x4 *)(xq + 1024) = old_b;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                old_a = *(__attribute__((address_space(3))) f32x4 *)(xr + 32 * lane);
+                old_b = *(__attribute__((address_space(3))) f32x4 *)(xr + 32 * lane + 16);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             if constexpr (ACC) { // (the old flow is zero in the columns outside the image, which are never stored)
                 uv[0] = old_a.x + uv[0], uv[1] = old_a.y + uv[1], uv[2] = old_a.z + uv[2], uv[3] = old_a.w + uv[3];
                 uv[4] = old_b.x + uv[4], uv[5] = old_b.y + uv[5], uv[6] = old_b.z + uv[6], uv[7] = old_b.w + uv[7];

@@ -40,8 +40,8 @@ pmc() { # name, kernel substring, skip, pmc_run args...
   python tools/pmc_parse.py $O/pmc_$n $k $skip | tee -a $O/summary/${TAG}_traffic_pmc.jsonl
 }
 pmc stream stream_kernel 3 4k stream lk_float
-pmc iter2 lk_iter_kernelILi4ELi1ELb0ELi2 2 4k stream lk_float 5
-pmc iter1 lk_iter_kernelILi4ELi1ELb0ELi1 1 4k stream lk_float 5
+pmc iter2 "lk_iter_kernel<4, 1, false, 2," 2 4k stream lk_float 5
+pmc iter1 "lk_iter_kernel<4, 1, false, 1," 1 4k stream lk_float 5
 pmc plain lk_level_kernel 1 4k plain lk_float
 pmc compat stream_kernel 3 4k stream compat_cpu
 # traffic per launch for bench.py's roofline.traffic (keys: bench.py line(): tkey)
