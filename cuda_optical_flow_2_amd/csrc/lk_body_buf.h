@@ -62,6 +62,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, in
 #ifndef OFX_LK_DEFER_STORE
 #define OFX_LK_DEFER_STORE 2
 #endif
+// The leaving window's rows out of an LDS ring (round 4).  In the accumulating launches 16 B/px of flow stream through the XCD's 4 MB
+// L2 between a row's first read (entering the vertical window) and its second (leaving it, 2R + 1 steps later): the second read
+// misses and goes to the fabric -- 391 MB of the launch's 1 600 MB of fabric reads (profiles/r04_ablation.txt batch 6).  A lane
+// keeps the finished dwords (prev, next) of the last 2R + 1 entering rows in 8 bytes per row of LDS of its own and takes the leaving
+// row from there: no load, no fabric traffic, no finish.  (R + 1) KB per wave; accumulating launches without deep fetch,
+// R <= 8.  OFX_LK_OUT_RING=0: both rows from memory, as the tick does (whose L2 holds them: it fetches 1.10 x its algorithmic reads).
+// MEASURED (profiles/r04_ablation.txt batch 6): fabric reads of the launch 1 601 -> 1 386 MB (traffic 1.35 x -> 1.23 x algorithmic), launch
+// 462 vs 459 us, 1080p and the pair-at-a-time path 1.6 % slower (the packed selectors it needs to stay within 128 VGPRs cost ~18 vector
+// instructions per row step): the launch is not bound by its fabric traffic either.  Bit-exact; OFF by default.
+#ifndef OFX_LK_OUT_RING
+#define OFX_LK_OUT_RING 0
+#endif
+template <int R, int ITER, bool DMA>
+constexpr bool lk_out_ring()
+{
+    return OFX_LK_OUT_RING && (ITER == 1 || ITER == 2 || ITER == 4) && !DMA && R <= 8;
+}
+template <int R, int ITER, bool DMA>
+constexpr int lk_ring_bytes()
+{
+    return lk_out_ring<R, ITER, DMA>() ? (R + 1) * 1024 : 0; // (two rows per 16-byte lane slot: the address is 16 * lane + a scalar)
+}
 #ifndef OFX_LK_ACC_LOAD_AUX
 #define OFX_LK_ACC_LOAD_AUX 0
 #endif
@@ -89,6 +111,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     constexpr int NS = 2 * R + 1;
     constexpr bool ACC = ITER == 1 || ITER == 2 || ITER == 4, WOUT = ITER >= 2, ROWWIN = ITER >= 4;
     constexpr bool DEFER = OFX_LK_DEFER_STORE == 1 || (OFX_LK_DEFER_STORE == 2 && ACC);
+    constexpr bool RING = lk_out_ring<R, ITER, DMA>(); // the leaving rows come out of the wave's LDS ring (xlds + kLkWaveLdsX)
 
     if (wave >= T.first_block[T.n]) return;
     int level = 0, hi = T.n;
@@ -121,12 +144,10 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     // column validity: bytes outside [0,w) read as zero, derivatives there are zero
     const bool ld_ok = INTERIOR || (cb >= 0 && cb < A.w);
     uint32_t bmask = INTERIOR ? 0xffffffffu : 0u;
-    int cm[4] = {-1, -1, -1, -1};
     if constexpr (!INTERIOR) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const bool in = (cb + j) >= 0 && (cb + j) < A.w;
-            cm[j] = in ? -1 : 0;
             bmask |= in ? (0xffu << (8 * j)) : 0u;
         }
     }
@@ -139,6 +160,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     const bool st_lo4 = c16 <= lim, st_lo2 = c16 == lim + 8, st_hi4 = c16 <= lim - 1024, st_hi2 = c16 == lim + 8 - 1024;
     // lane offsets of the two stores; a lane that has nothing to store points outside the resource (the store is dropped)
     uint32_t vo_lo = st_lo4 ? l16 : (uint32_t)kOob, vo_hi = st_hi4 ? l16 + 1024u : (uint32_t)kOob;
+    // (a full tile: every lane's first chunk exists -- interior tiles use l16 itself, the register the exchange keeps anyway)
     const bool ragged = __any(st_lo2 || st_hi2) != 0; // a level of odd width ends inside a chunk: that lane stores one pixel
     const lds_ptr xl_w = (lds_ptr)xlds + 32 * lane;
     const lds_ptr xl_base = (lds_ptr)xlds + 32 * G::LO_LANE;
@@ -307,6 +329,10 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     RowPk<MODE> wp[3];
     const s2 two = pk_two();
     refresh_map(y_first - 1);
+    // RING: slot ((r - (y_lo0 - 1)) mod NS) holds image row r; this lane's 8 bytes of it are (prev, next), finished
+    // (rows 2j and 2j + 1 share a lane's 16 bytes of KB j, so that the address is the lane's 16 * lane -- a register the exchange keeps
+    // anyway -- plus a scalar: a pointer of its own would be the 129th VGPR of a kernel that must fit 128)
+    auto ring_at = [&](int slot) -> lds_ptr { return (lds_ptr)xlds + (kLkWaveLdsX + (slot >> 1) * 1024 + (slot & 1) * 8) + lane_off_var(l16); };
     {
         uint32_t pi, ni, po = 0u, no = 0u;
 #pragma unroll
@@ -314,8 +340,10 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             load_pair(y_lo0 - 1 + t, false, pi, ni);
             if constexpr (H > 0) load_pair(y_first - 1 + t, true, po, no);
             unpack_pk(pi, ni, po, no, wp[t]);
+            if constexpr (RING) *(__attribute__((address_space(3))) u32x2 *)(ring_at(t % NS)) = u32x2{pi, ni};
         }
     }
+    [[maybe_unused]] int rslot = 3 % NS; // the slot of the row the next step adds (and of the one it takes out of the ring)
     if constexpr (DMA) { // the rows step 0 takes at its end (the b rows of step 1): y_lo0 + 2 and the high stream's
         const int ro0 = (H > 1 && 1 < H) ? y_first + 2 : y_lo0 - NS + 2;
         issue_rows(0, y_lo0 + 2, ro0);
@@ -340,7 +368,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
 #if defined(OFX_X_NOSTORE) // timing experiment: the row is exchanged but never stored
         asm volatile("" : : "v"(xlo), "v"(xhi), "s"(fso));
 #else
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xlo), rs_flow, vo_lo, fso, OFX_LK_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xlo), rs_flow, INTERIOR ? lane_off_var(l16) : vo_lo, fso, OFX_LK_STORE_AUX);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xhi), rs_flow, vo_hi, fso, OFX_LK_STORE_AUX);
 #endif
         if (__builtin_expect(ragged, 0)) { // the one lane whose chunk holds a single pixel
@@ -378,10 +406,19 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
             if (yy + 2 - map_base >= 64) refresh_map(yo + 2); // (yo + 2 is the lowest row still to be looked up)
             const int po_in = row_off(yy + 2), po_out = row_off_out(ro);
             pf_ip = fetch_prev(po_in);
-            pf_op = fetch_prev(po_out);
             pf_in = fetch_next(yy + 2, po_in);
-            // (a row of the leaving window before y_first - 1 is never used and may lie below the table: its pixels are zeros)
-            if (ro >= y_first - 1) pf_on = fetch_next(ro, po_out);
+#ifndef OFX_X_NO_OUTROWS // (diagnostic builds, profiles/r04_ablation.txt batch 6: which loads the launch's fabric reads belong to)
+            if (RING && s >= NS - 3) {
+                // the leaving row entered NS steps ago (or with the priming rows): its finished dwords wait in the ring
+                const u32x2 q = *(const __attribute__((address_space(3))) u32x2 *)(ring_at(rslot));
+                pf_op = q.x;
+                pf_on.sh = q.y;
+            } else {
+                pf_op = fetch_prev(po_out);
+                // (a row of the leaving window before y_first - 1 is never used and may lie below the table: its pixels are zeros)
+                if (ro >= y_first - 1) pf_on = fetch_next(ro, po_out);
+            }
+#endif
         }
         const bool emit = s >= PR;
         // ACC: the flow this row adds to, as it lies (this lane's 4 pixels), fetched with the step's rows
@@ -392,18 +429,22 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 const int fnat = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep - x0 * 8); // offset of the row's pixel 0
                 // (OFX_LK_ACC_LOAD_AUX: cache-policy bits of the old flow's loads.  2 = nt -- "read once, do not displace the image rows the
                 // trailing window re-reads" -- measured 20 % SLOWER at 4K / 5 iterations: 554 vs 457 us, profiles/r04_ablation.txt batch 4)
+#ifdef OFX_X_NO_OLDFLOW
+                old_a = old_b = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (false)
+#endif
                 if constexpr (INTERIOR && OFX_LK_ACC_XLOAD) {
                     // the old flow in the EXCHANGED layout, as the stores write it: each of the two loads covers 1 KB without gaps
                     // (in place, a lane's two 16-byte halves make every instruction touch all sixteen lines of the row and use half of
                     // each).  Put back in place through the exchange row right before the add.
                     const int fx = __builtin_amdgcn_readfirstlane(fso0 + (s - PR) * fstep);
-                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, vo_lo, fx, OFX_LK_ACC_LOAD_AUX));
+                    old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, lane_off_var(l16), fx, OFX_LK_ACC_LOAD_AUX));
                     old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, vo_hi, fx, OFX_LK_ACC_LOAD_AUX));
                 } else if constexpr (INTERIOR) {
                     old_a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off, fnat, OFX_LK_ACC_LOAD_AUX));
                     old_b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_flow, nat_off + 16u, fnat, OFX_LK_ACC_LOAD_AUX));
                 } else { // (per pixel: a level of odd width ends inside a 16-byte piece)
-                    auto off = [&](int j) { return cm[j] ? nat_off + 8u * (uint32_t)j : (uint32_t)kOob; };
+                    auto off = [&](int j) { return ((bmask >> (8 * j)) & 1u) ? nat_off + 8u * (uint32_t)j : (uint32_t)kOob; };
                     const u32x2 p0 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(0), fnat, OFX_LK_ACC_LOAD_AUX), p1 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(1), fnat, OFX_LK_ACC_LOAD_AUX);
                     const u32x2 p2 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(2), fnat, OFX_LK_ACC_LOAD_AUX), p3 = __builtin_amdgcn_raw_buffer_load_b64(rs_flow, off(3), fnat, OFX_LK_ACC_LOAD_AUX);
                     old_a = __builtin_bit_cast(f32x4, u32x4{p0.x, p0.y, p1.x, p1.y});
@@ -417,7 +458,11 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
         // (one scalar multiplier pair for all columns.  readfirstlane, not pin_scalar: hipcc's uniformity analysis does not see
         // that this value -- or the store offset below -- is wave-uniform, and an "s" constraint on it fails to compile)
         if constexpr (INTERIOR) rowm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rowm);
-        const uint32_t mm[4] = {(uint32_t)cm[0] & rowm, (uint32_t)cm[1] & rowm, (uint32_t)cm[2] & rowm, (uint32_t)cm[3] & rowm};
+        // (edge tiles: a column's mask comes out of the byte mask -- one sign-extending bit-field extract -- instead of living in four
+        // registers of its own: the accumulating launches sit on the 128-VGPR line; interior tiles: cm is the constant -1)
+        uint32_t mm[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mm[j] = INTERIOR ? rowm : ((uint32_t)__builtin_amdgcn_sbfe((int)bmask, 8 * j, 1) & rowm);
         s2 ix[4], iy[4], it[4];
         derivs_pk(wp[k], wp[(k + 1) % 3], wp[(k + 2) % 3], two, ix, iy, it);
         accumulate_pk(ix, iy, it, mm, vxx, vyy, vxy, vxt, vyt);
@@ -444,7 +489,17 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 if (__builtin_expect(!all_in, 0)) o_n = row(4), o_no = row(5);
                 unpack_pk(finish_row(a_p), take_one(yy + 2, false, a_n, o_n), finish_row(a_po), take_one(ro, true, a_no, o_no), wp[k]);
             } else {
-                unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+                if constexpr (RING) {
+                    const uint32_t p_in = finish_row(pf_ip), n_in = finish_next(pf_in);
+                    uint32_t p_out, n_out;
+                    if (s >= NS - 3) p_out = pf_op, n_out = pf_on.sh;
+                    else p_out = finish_row(pf_op), n_out = finish_next(pf_on);
+                    unpack_pk(p_in, n_in, p_out, n_out, wp[k]);
+                    *(__attribute__((address_space(3))) u32x2 *)(ring_at(rslot)) = u32x2{p_in, n_in};
+                    rslot = rslot + 1 == NS ? 0 : rslot + 1;
+                } else {
+                    unpack_pk(finish_row(pf_ip), finish_next(pf_in), finish_row(pf_op), finish_next(pf_on), wp[k]);
+                }
             }
             pin_row(wp[k]);
         };
@@ -504,7 +559,11 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
                 const int yw = yy - R; // this step's output row
                 const uint32_t wn = warp_row_finish(WM);
                 const int wso = __builtin_amdgcn_readfirstlane(s > PR ? (yw - 1 - A.row0) * A.pitch : kOob);
+#ifdef OFX_X_NO_WSTORE
+                asm volatile("" : : "v"(wn), "s"(wso));
+#else
                 __builtin_amdgcn_raw_buffer_store_b32(wn, rs_wout, wvo, wso, 0);
+#endif
                 const float fu[4] = {uv[0], uv[2], uv[4], uv[6]}, fv[4] = {uv[1], uv[3], uv[5], uv[7]};
                 warp_row_prepare<ROWWIN>(rs_wsrc, A.warp_scale, A.w, A.h, A.pitch, A.row0, A.row_end, cb, yw, wnpx, fu, fv, WM, wmiss);
             }

@@ -18,9 +18,19 @@
 
 namespace ofx_dev {
 
+// OFX_WARP_PACK_SEL: the four pixels' byte selectors in ONE register between the stages (4 bits per pixel: xi - xb and x1 - xb, each
+// 0 .. 3) instead of four -- three VGPRs for a kernel that sits on the 128-register line (the LDS ring of lk_body_buf.h needs them),
+// ~16 more vector instructions per row step to pack and unpack.
+#ifndef OFX_WARP_PACK_SEL
+#define OFX_WARP_PACK_SEL 0 // (on only together with OFX_LK_OUT_RING=1)
+#endif
 struct WarpRowState {      // a row of a lane between the two stages
     float fx[4], fy[4];    // the fractions of the source coordinates
+#if OFX_WARP_PACK_SEL
+    uint32_t selp;         // bits 4k .. 4k+1: xi - xb of pixel k, bits 4k+2 .. 4k+3: x1 - xb
+#else
     uint32_t sel[4];       // per pixel the byte selector (xi - xb, x1 - xb, zero, zero) into its two dwords (general rows only)
+#endif
     uint32_t ra[4], rb[4]; // per pixel the dwords of rows yi and y1 (loads in flight between the stages)
     int general;           // wave-uniform: some pixel of the wave's row has its taps at the right end of a source row (see below)
 };
@@ -40,7 +50,12 @@ struct WarpRowState {      // a row of a lane between the two stages
 __device__ __forceinline__ void warp_row_clear(WarpRowState &M)
 {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.sel[k] = 0x0c0c0c0cu, M.ra[k] = M.rb[k] = 0u;
+    for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.ra[k] = M.rb[k] = 0u;
+#if OFX_WARP_PACK_SEL
+    M.selp = 0u; // (both taps byte 0 of a zero dword: the pending row of the first emitting step is stored nowhere)
+#else
+    for (int k = 0; k < 4; ++k) M.sel[k] = 0x0c0c0c0cu;
+#endif
     M.general = 1;
 }
 
@@ -77,12 +92,23 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
     const int xlim = min(pitch - 4, w - 2);
     M.general = !OFX_WARP_FAST_ROWS || __any(max(max(xi[0], xi[1]), max(xi[2], xi[3])) > xlim) != 0;
     if (__builtin_expect(M.general, 0)) {
+#if OFX_WARP_PACK_SEL
+        M.selp = 0u;
+#endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int xb = min(xi[k], pitch - 4); // the dword stays inside the row pitch
+#ifdef OFX_X_NO_TAPS // (diagnostic build: no tap loads)
+            M.ra[k] = (uint32_t)(ya[k] * pitch + xb), M.rb[k] = (uint32_t)(yb[k] * pitch + xb);
+#else
             M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(ya[k] * pitch + xb), 0, 0);
             M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(yb[k] * pitch + xb), 0, 0);
+#endif
+#if OFX_WARP_PACK_SEL
+            M.selp |= ((uint32_t)(xi[k] - xb) | ((uint32_t)(min(xi[k] + 1, wmax) - xb) << 2)) << (4 * k);
+#else
             M.sel[k] = (uint32_t)(xi[k] - xb) | ((uint32_t)(min(xi[k] + 1, wmax) - xb) << 8) | 0x0c0c0000u;
+#endif
         }
     } else {
 #pragma unroll
@@ -107,7 +133,14 @@ __device__ __forceinline__ uint32_t warp_row_finish(const WarpRowState &M)
     };
     if (__builtin_expect(M.general, 0)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) blend(k, __builtin_amdgcn_perm(0u, M.ra[k], M.sel[k]), __builtin_amdgcn_perm(0u, M.rb[k], M.sel[k]));
+        for (int k = 0; k < 4; ++k) {
+#if OFX_WARP_PACK_SEL
+            const uint32_t sk = ((M.selp >> (4 * k)) & 3u) | (((M.selp >> (4 * k + 2)) & 3u) << 8) | 0x0c0c0000u;
+#else
+            const uint32_t sk = M.sel[k];
+#endif
+            blend(k, __builtin_amdgcn_perm(0u, M.ra[k], sk), __builtin_amdgcn_perm(0u, M.rb[k], sk));
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) blend(k, M.ra[k], M.rb[k]);

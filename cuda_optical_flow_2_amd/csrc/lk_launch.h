@@ -67,9 +67,10 @@ __global__ __launch_bounds__(64, OFX_LK_MIN_WAVES(R)) void lk_level_kernel(const
 #define OFX_WIDE_ITER_MIN_WAVES 2
 #endif
 template <int R, int MODE, bool FAST, int ITER, bool DMA = false, int NC = 4>
-__global__ __launch_bounds__(64, NC == 8 ? OFX_WIDE_ITER_MIN_WAVES : OFX_ITER_MIN_WAVES(ITER)) void lk_iter_kernel(const LkTable T)
+// (with the LDS ring of the leaving rows the accumulating launches fit 128 VGPRs without scratch for R <= 7: four waves per SIMD)
+__global__ __launch_bounds__(64, NC == 8 ? OFX_WIDE_ITER_MIN_WAVES : (lk_out_ring<R, ITER, DMA>() && R <= 7 ? 4 : OFX_ITER_MIN_WAVES(ITER))) void lk_iter_kernel(const LkTable T)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t xlds[NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLdsX)];
+    __shared__ __attribute__((aligned(16))) uint8_t xlds[NC == 8 ? kLkWaveLdsW : (DMA ? kLkWaveLdsDma : kLkWaveLdsX + lk_ring_bytes<R, ITER, DMA>())];
     const int wave = (int)blockIdx.x, lane = (int)threadIdx.x;
     if constexpr (NC == 8) {
         static_assert(!DMA, "the wide march has no deep fetch");
