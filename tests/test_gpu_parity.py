@@ -1454,3 +1454,61 @@ def test_sharded_streamed_iterations_equal_the_unsharded_path(eng, cfg):
     if (win // 2 + 1) * iters > win // 2 + 1 + 8:   # (the default plan's margin of 8 rows does not cover the iterations' rows)
         with pytest.raises(OfxError):
             eng.Session(w, h, L, win, "lk_float", shard=ShardPlan(w, h, L, win, 1, R), local_corner=True, iters=iters)
+
+
+_WIDE_SNIPPET = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from cuda_optical_flow_2_amd import engine as eng, synth
+
+def same(a, b):
+    return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
+
+for (w, h, L, win, B) in ((1280, 720, 4, 9, 4), (1000, 562, 3, 7, 2), (640, 480, 3, 15, 2)):
+    nf = 3 * B + 2
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=31)[1]).cuda() for i in range(nf)]
+    frames[3] = torch.from_numpy(synth.random_pair(w, h, 7)[0]).cuda()   # (non-finite flows, every clamp)
+    s = eng.Session(w, h, L, win, "lk_float", stream_batch=B)
+    plain = eng.Session(w, h, L, win, "lk_float")
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    s.stream_begin()
+    done = -1
+    got = {{}}
+    def snap(d):
+        for p in range(max(1, d - B + 1), d + 1):
+            if p not in got:
+                got[p] = [s.flow_of(p, k)[0].clone() for k in range(L)]
+    for f in frames:
+        d = s.stream_submit(f)
+        if d >= 1: snap(d)
+    while True:
+        d = s.stream_drain()
+        if d == -2: break
+        if d >= 1: snap(d)
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        for k in range(L):
+            assert i in got and same(got[i][k], plain.flow(k)[0]), (w, h, win, i, k)
+        plain.swap()
+    s.close(); plain.close()
+print("wide ok")
+"""
+
+
+def test_march_with_eight_columns_per_lane_is_bit_identical(eng):
+    """csrc/lk_body_wide.h (round 4): the LK march with eight columns per lane is selected per process (OFX_LK_COLS=8 for the stream
+    tick, OFX_LK_PLAIN_COLS=8 for the pair-at-a-time launch; measured slower, so not the default).  A child process with both set
+    streams three configurations (odd width, windows 7 / 9 / 15, a uniform-random frame in the middle) and compares every pair and
+    level of the tick with the plain sequence: first the tick on the wide march against the plain launch on the narrow one, then
+    the other way round -- the narrow forms are the ones every other test pins to the oracle."""
+    import subprocess
+    import sys as _sys
+
+    env = dict(os.environ, OFX_LK_COLS="8", OFX_LK_PLAIN_COLS="0")
+    code = _WIDE_SNIPPET.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    env = dict(os.environ, OFX_LK_COLS="4", OFX_LK_PLAIN_COLS="8")   # the narrow tick against the wide pair-at-a-time launch
+    r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
