@@ -1465,7 +1465,7 @@ from cuda_optical_flow_2_amd import engine as eng, synth
 def same(a, b):
     return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item())
 
-for (w, h, L, win, B) in ((1280, 720, 4, 9, 4), (1000, 562, 3, 7, 2), (640, 480, 3, 15, 2)):
+for (w, h, L, win, B) in ((1280, 720, 4, 9, 4), (1000, 564, 3, 7, 2), (640, 480, 3, 15, 2)):
     nf = 3 * B + 2
     frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=31)[1]).cuda() for i in range(nf)]
     frames[3] = torch.from_numpy(synth.random_pair(w, h, 7)[0]).cuda()   # (non-finite flows, every clamp)

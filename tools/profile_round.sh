@@ -37,7 +37,7 @@ pmc() { # name, kernel substring, skip, pmc_run args...
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n/$C -- python tools/pmc_run.py "$@" > $O/pmc_${n}_$C.out 2> $O/pmc_${n}_$C.err
   done
-  python tools/pmc_parse.py $O/pmc_$n $k $skip | tee -a $O/summary/${TAG}_traffic_pmc.jsonl
+  python tools/pmc_parse.py $O/pmc_$n "$k" $skip | tee -a $O/summary/${TAG}_traffic_pmc.jsonl
 }
 pmc stream stream_kernel 3 4k stream lk_float
 pmc iter2 "lk_iter_kernel<4, 1, false, 2," 2 4k stream lk_float 5
