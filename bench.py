@@ -949,6 +949,20 @@ class Run:
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps * 1e3
+        # the 3x3 correlations of a level (channel 0 of a 3-channel image -> one plane; SURVEY 8d: 3 read + s written per pixel,
+        # s = 1 for cpu::conv_3ch_to_1ch's u8 result, 4 for gpu::conv_3ch_1ch_tiled_uchar_float's float plane; four calls per level)
+        import numpy as _np
+        img3 = torch.from_numpy(self.synth.to_3ch(self.host_frames(wa, ha)[1])).cuda()
+        c8 = torch.empty((ha, wa), dtype=torch.uint8, device="cuda")
+        cf = torch.empty((ha, wa), dtype=torch.float32, device="cuda")
+        dx = _np.ascontiguousarray(_np.array([-1, 0, 1, -2, 0, 2, -1, 0, 1], _np.float32))
+        t_c8 = timed(lambda: _l.check(L_.ofx_conv_3ch_1ch_u8(img3.data_ptr(), wa, ha, c8.data_ptr(), dx.ctypes.data, 3, 3, st_), "conv u8"), 10)
+        t_cf = timed(lambda: _l.check(L_.ofx_conv_3ch_1ch_f32(img3.data_ptr(), wa, ha, cf.data_ptr(), dx.ctypes.data, 3, 3, st_), "conv f32"), 10)
+        out["conv_3ch_to_1ch_4k_3x3"] = dict(roofline_block(4 * wa * ha, t_c8, kernel="ofx_conv_3ch_1ch_u8 (cpu::conv_3ch_to_1ch, gpu::conv_3ch_1ch_constant)",
+                                                            avg_launch_us=round(t_c8, 1), algorithmic_bytes_per_launch=4 * wa * ha), four_calls_us=round(4 * t_c8, 1))
+        out["conv_3ch_1ch_float_4k_3x3"] = dict(roofline_block(7 * wa * ha, t_cf, kernel="ofx_conv_3ch_1ch_f32 (gpu::conv_3ch_1ch_tiled_uchar_float)",
+                                                               avg_launch_us=round(t_cf, 1), algorithmic_bytes_per_launch=7 * wa * ha), four_calls_us=round(4 * t_cf, 1))
+        del img3, c8, cf
         for win in (9, 19):
             t_u = timed(lambda: _l.check(L_.ofx_srm_u8(a8.data_ptr(), b8.data_ptr(), wa, ha, win, win, d32.data_ptr(), st_), "srm_u8"), 10)
             t_f = timed(lambda: _l.check(L_.ofx_srm_f32(af.data_ptr(), bf.data_ptr(), wa, ha, win, win, df.data_ptr(), st_), "srm_f32"), 10)

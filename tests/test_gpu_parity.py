@@ -1074,6 +1074,25 @@ def test_window_sums_on_the_march_equal_the_oracle(gpu, oracle, shape):
         assert_same(gpu.srm_1ch_float(fa, fb, ww, wh), oracle.srm_1ch_f32(fa, fb, ww, wh), f"gpu::srm_1ch_float {w}x{h} {ww}x{wh}")
 
 
+@pytest.mark.parametrize("shape", [(16, 9), (17, 5), (255, 33), (1000, 21), (260, 4)])
+def test_channel0_correlations_four_pixels_per_thread_equal_the_oracle(gpu, oracle, shape):
+    """gpu::conv_3ch_1ch_constant / _tiled (int accumulator truncated after every tap, OptFlowGpu.cu:380-425 == OptFlowCPU.cpp:75-109)
+    and gpu::conv_3ch_1ch_tiled_uchar_float (float accumulator, :1040-1090) since round 4 give a thread four adjacent pixels and
+    fetch their channel-0 bytes as dwords (csrc/primitives.hip, conv_3ch_1ch_x4_kernel); the threads at the image's edges keep the
+    pixel-by-pixel loop.  Every mask of the reference's tables plus fractional, negative, 2- and 4-wide ones, on widths that end
+    inside a thread's four pixels, uniform-random bytes: bit for bit."""
+    w, h = shape
+    rng = np.random.default_rng(w * 131 + h)
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    masks = [(gpu.Dx_3x3, 3, 3), (gpu.Dy_3x3, 3, 3), (gpu.Dt_3x3, 3, 3), (gpu.GAUS_KERNEL_3x3, 3, 3), (gpu.GAUS_KERNEL_5x5, 5, 5), (gpu.Dx_5x5, 5, 5),
+             (np.array([0.3, -1.7, 2.2, 0.0, -0.45, 1.0], np.float32), 2, 3), (rng.normal(size=12).astype(np.float32) * 3, 4, 3),
+             (rng.normal(size=15).astype(np.float32), 5, 3), (rng.normal(size=27).astype(np.float32), 3, 9)]
+    for m, mw, mh in masks:
+        m = np.asarray(m, np.float32)
+        assert_same(gpu.conv_3ch_1ch(img, m, mw, mh), oracle.conv_3ch_to_1ch(img, m, mw, mh), f"conv u8 {w}x{h} mask {mw}x{mh}")
+        assert_same(gpu.conv_3ch_1ch_float(img, m, mw, mh), oracle.conv_3ch_to_1ch_f32(img, m, mw, mh), f"conv f32 {w}x{h} mask {mw}x{mh}")
+
+
 def test_gpu_namespace_float_primitives(gpu, oracle):
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
