@@ -128,11 +128,13 @@ def roofline_block(nbytes, us, **more):
 
 
 def kernel_source_hash():
-    """sha256 (16 hex digits) over the kernel sources of the library: what profiles/traffic_latest.json was measured for"""
+    """sha256 (16 hex digits) over the sources that define the LK / stream launches whose traffic profiles/traffic_latest.json holds
+    (the march, its planner and launchers, corner and pyramid stages, the session that plans the ticks, the ABI header) -- not the
+    stand-alone primitives, which those launches do not contain"""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "cuda_optical_flow_2_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".h", ".hip", ".cpp")):
+        if name.startswith(("lk_", "corner", "pyr", "stages_body", "session", "ofx_internal")) and name.endswith((".h", ".hip", ".cpp")):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), "rb").read())
     h.update(open(os.path.join(ROOT, "include", "ofx.h"), "rb").read())
