@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void srm_u8_march_kernel(const SrmArgs A)
 // formed ONCE per pixel (the plain kernel forms each of them ww * wh times and fetches 2 * ww * wh floats per output from global
 // memory).  A wave walks down a strip of a 256-column tile; the products of the newest image row go into slot (row mod wh) of a ring
 // of wh rows in the wave's LDS; a lane then accumulates its four adjacent outputs: per window row it reads the ww + 3 products they
-// cover and feeds four independent accumulators in tap order (plain v_add_f32: the cheap issue class).  A tap outside the image is
+// cover and feeds four independent accumulators in tap order (plain v_add_f32: the cheap issue class); four output rows per step share
+// the product rows they have in common (each row of products is read from LDS once per step).  A tap outside the image is
 // skipped by the reference; here it adds the +0.0f stored for it, which leaves a float accumulator that started at +0.0f unchanged
 // bit for bit (it can never be -0.0f).  12 B/px per call (2 floats read, one written).
 struct SrmFArgs {
@@ -161,6 +162,7 @@ struct SrmFArgs {
     int tiles_x, strips, strip_h, out_w;
 };
 
+constexpr int kSrmFRps = 4;          // output rows per step of the float march
 constexpr int kSrmFRow = 256 + 64; // floats per ring row (the reads of the lanes past the tile's last output land in the pad)
 
 // (one wave per block: the ring of a 19x19 window is 24 KB, and a block's LDS is what limits how many waves a CU holds)
@@ -177,8 +179,8 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
     const int x0 = tile * A.out_w - ox;
     const int cb = x0 + 4 * lane;
     const int ys = strip * A.strip_h, ye = min(ys + A.strip_h, h);
-    float *ring = ring_all + (size_t)wv * (size_t)wh * kSrmFRow;
-    for (int r = 0; r < wh; ++r)
+    float *ring = ring_all + (size_t)wv * (size_t)(wh + kSrmFRps - 1) * kSrmFRow;
+    for (int r = 0; r < wh + kSrmFRps - 1; ++r)
         if (lane < 16) *(float4 *)(ring + r * kSrmFRow + 256 + 4 * lane) = float4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const __amdgpu_buffer_rsrc_t ra = srm_rsrc(A.a, (unsigned)w * (unsigned)h * 4u), rb = srm_rsrc(A.b, (unsigned)w * (unsigned)h * 4u);
@@ -199,34 +201,52 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
         v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, co[3], o, 0));
         return v;
     };
-    // products of image row y into its ring slot; rows and columns outside the image give +0.0f (0 * 0)
-    auto put_row = [&](int y, const float4 pa, const float4 pb) {
-        int slot = y % wh;
-        if (slot < 0) slot += wh;
+    // RPS output rows per step share their product rows: a row of products is read from LDS once and feeds the accumulators of every
+    // output row whose window holds it -- each output still receives its own taps in row-major order
+    constexpr int RPS = kSrmFRps;
+    const int nslots = wh + RPS - 1;
+    auto slot_of = [&](int r) {
+        int sl = r % nslots;
+        return sl < 0 ? sl + nslots : sl;
+    };
+    auto put_row_s = [&](int y, const float4 pa, const float4 pb) {
         const bool in_img = (uint32_t)y < (uint32_t)h;
         float4 p{pa.x * pb.x, pa.y * pb.y, pa.z * pb.z, pa.w * pb.w};
         if (!in_img) p = float4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (co[j] == (uint32_t)kSrmOob) (&p.x)[j] = 0.0f; // (a NaN / Inf next to the border must not leak into a skipped tap)
-        *(float4 *)(ring + slot * kSrmFRow + 4 * lane) = p;
+        *(float4 *)(ring + slot_of(y) * kSrmFRow + 4 * lane) = p;
     };
-    for (int y = ys - oy; y < ys + ry; ++y) put_row(y, fetch(ra, y), fetch(rb, y));
+    // priming, eight rows' loads in flight at a time (one wave per SIMD is all the ring's LDS allows: a load per iteration would
+    // expose a memory round trip per primed row -- 18 of them for a 19-row window)
+    for (int y = ys - oy; y < ys + ry; y += 8) {
+        float4 pa[8], pb[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pa[t] = fetch(ra, y + t), pb[t] = fetch(rb, y + t);
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (y + t < ys + ry) put_row_s(y + t, pa[t], pb[t]);
+    }
     const int xo = x0 + ox + 4 * lane;
     const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
     const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
     const bool ragged = __any(nval > 0 && nval < 4) != 0;
-    float4 na = fetch(ra, ys + ry), nb = fetch(rb, ys + ry);
-    for (int y = ys; y < ye; ++y) {
-        const float4 ca = na, cb4 = nb;
-        na = fetch(ra, y + 1 + ry), nb = fetch(rb, y + 1 + ry); // the next step's row, a step ahead
-        put_row(y + ry, ca, cb4);
+    float4 na[RPS], nb[RPS];
+#pragma unroll
+    for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, ys + ry + o), nb[o] = fetch(rb, ys + ry + o);
+    for (int y = ys; y < ye; y += RPS) {
+#pragma unroll
+        for (int o = 0; o < RPS; ++o) put_row_s(y + ry + o, na[o], nb[o]);
+#pragma unroll
+        for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, y + RPS + ry + o), nb[o] = fetch(rb, y + RPS + ry + o); // the next step's rows, a step ahead
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-        int slot = (y - oy) % wh;
-        if (slot < 0) slot += wh;
-        for (int p = 0; p < wh; ++p) { // window rows top to bottom
+        float acc[RPS][4];
+#pragma unroll
+        for (int o = 0; o < RPS; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0.0f;
+        int slot = slot_of(y - oy);
+        for (int p = 0; p < nslots; ++p) { // product rows y - oy + p, top to bottom
             const float *src = ring + slot * kSrmFRow + 4 * lane;
             if constexpr (WW > 0) {
                 float t[WW + 3];
@@ -238,33 +258,62 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
                     if (4 * k + 2 < WW + 3) t[4 * k + 2] = q.z;
                     if (4 * k + 3 < WW + 3) t[4 * k + 3] = q.w;
                 }
+                if (p >= RPS - 1 && p < wh) {
+                    // the row lies in every output row's window: sixteen independent accumulators take tap q before any takes tap
+                    // q + 1 (an accumulator's own order stays left to right; the distance between its dependent adds is what a lone
+                    // wave needs to issue at rate)
 #pragma unroll
-                for (int q = 0; q < WW; ++q) { // taps left to right, four outputs side by side
-                    acc0 += t[q];
-                    acc1 += t[q + 1];
-                    acc2 += t[q + 2];
-                    acc3 += t[q + 3];
+                    for (int q = 0; q < WW; ++q) {
+#pragma unroll
+                        for (int o = 0; o < RPS; ++o) {
+                            acc[o][0] += t[q];
+                            acc[o][1] += t[q + 1];
+                            acc[o][2] += t[q + 2];
+                            acc[o][3] += t[q + 3];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int o = 0; o < RPS; ++o) {
+                        if (p >= o && p - o < wh) { // (wave-uniform) this product row lies in output row y + o's window
+#pragma unroll
+                            for (int q = 0; q < WW; ++q) { // taps left to right, four outputs side by side
+                                acc[o][0] += t[q];
+                                acc[o][1] += t[q + 1];
+                                acc[o][2] += t[q + 2];
+                                acc[o][3] += t[q + 3];
+                            }
+                        }
+                    }
                 }
             } else {
-                for (int q = 0; q < ww; ++q) {
-                    acc0 += src[q];
-                    acc1 += src[q + 1];
-                    acc2 += src[q + 2];
-                    acc3 += src[q + 3];
+#pragma unroll
+                for (int o = 0; o < RPS; ++o) {
+                    if (p >= o && p - o < wh) {
+                        for (int q = 0; q < ww; ++q) {
+                            acc[o][0] += src[q];
+                            acc[o][1] += src[q + 1];
+                            acc[o][2] += src[q + 2];
+                            acc[o][3] += src[q + 3];
+                        }
+                    }
                 }
             }
-            slot = slot + 1 == wh ? 0 : slot + 1;
+            slot = slot + 1 == nslots ? 0 : slot + 1;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int so = __builtin_amdgcn_readfirstlane(y * w * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, acc0), __builtin_bit_cast(uint32_t, acc1), __builtin_bit_cast(uint32_t, acc2),
-                                                       __builtin_bit_cast(uint32_t, acc3)}, rd, st_off, so, 2 /* nt */);
-        if (__builtin_expect(ragged, 0)) {
-            const float ov[4] = {acc0, acc1, acc2, acc3};
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, ov[j]), rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
+        for (int o = 0; o < RPS; ++o) {
+            if (y + o >= ye) break;
+            const int so = __builtin_amdgcn_readfirstlane((y + o) * w * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(uint32_t, acc[o][0]), __builtin_bit_cast(uint32_t, acc[o][1]),
+                                                           __builtin_bit_cast(uint32_t, acc[o][2]), __builtin_bit_cast(uint32_t, acc[o][3])}, rd, st_off, so, 2 /* nt */);
+            if (__builtin_expect(ragged, 0)) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc[o][j]), rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
+            }
         }
     }
 }
@@ -310,7 +359,7 @@ int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int w
 
 int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, int wh, float *d_dst, hipStream_t st)
 {
-    if (w < 8 || ww < 1 || wh < 1 || ww > 57 || wh > 48 || (long long)w * h * 4 >= (1ll << 31)) return OFX_E_UNSUPPORTED;
+    if (w < 8 || ww < 1 || wh < 1 || ww > 57 || wh > 45 || (long long)w * h * 4 >= (1ll << 31)) return OFX_E_UNSUPPORTED;
     SrmFArgs A{};
     A.a = d_a, A.b = d_b, A.dst = d_dst, A.w = w, A.h = h, A.ww = ww, A.wh = wh;
     A.out_w = (256 - (ww - 1)) & ~3;
@@ -324,10 +373,11 @@ int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, 
     static const int min_strip = env_pos("OFX_SRMF_MIN_STRIP", 0);
     const int min_h = min_strip ? min_strip : 8;
     if (strip_h < min_h) strip_h = min_h;
+    strip_h = (strip_h + kSrmFRps - 1) / kSrmFRps * kSrmFRps; // whole steps
     A.strip_h = strip_h;
     A.strips = ofx_div_up(h, strip_h);
     const int blocks = A.tiles_x * A.strips;
-    const size_t lds = (size_t)wh * kSrmFRow * sizeof(float);
+    const size_t lds = (size_t)(wh + kSrmFRps - 1) * kSrmFRow * sizeof(float);
     switch (ww) {
 #define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL(srm_f32_march_kernel<N>, dim3((unsigned)blocks), dim3(64), lds, st, A); break;
         OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
