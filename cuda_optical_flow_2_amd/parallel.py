@@ -214,6 +214,7 @@ class ShardedFlow:
     # ---- stream pipeline (corner == "local", HIP sessions): one launch per frame on every rank, nothing between ranks
     def stream_begin(self):
         assert self.corner == "local", "the sharded stream pipeline needs the corner flows computed locally"
+        self._pending = None
         self.session.stream_begin()
 
     def stream_submit(self, frame) -> int:
@@ -225,6 +226,10 @@ class ShardedFlow:
         return self.session.stream_submit_frames(frames)
 
     def stream_drain(self) -> int:
+        if getattr(self, "_pending", None) is not None:   # a tick whose exchange overlapped the launch before it: submit it first
+            done = self._submit_pending()
+            if done >= 1:
+                return done
         return self.session.stream_drain()
 
     # ---- frames that ARRIVE sharded, through the stream pipeline (halo_mode == "stream_exchange") ------------------------------
@@ -286,9 +291,15 @@ class ShardedFlow:
             return
         recv, send = self._exchange_lists()
         ops, inbox = [], []
+        packed = {}   # (the rank that owns the patch sends the same piece to every other rank: packed once)
+
+        def piece(a, b, cols):
+            if (a, b, cols) not in packed:
+                packed[(a, b, cols)] = stack[:, a - o0: b - o0, :cols].reshape(-1).contiguous()
+            return packed[(a, b, cols)]
         for peer in sorted({x[0] for x in send}):
-            parts = [stack[:, a - o0: b - o0, :cols].reshape(-1) for pr, a, b, cols in send if pr == peer]
-            ops.append(dist.P2POp(dist.isend, parts[0].contiguous() if len(parts) == 1 else torch.cat(parts), peer))
+            parts = [piece(a, b, cols) for pr, a, b, cols in send if pr == peer]
+            ops.append(dist.P2POp(dist.isend, parts[0] if len(parts) == 1 else torch.cat(parts), peer))
         for peer in sorted({x[0] for x in recv}):
             pieces = [(a, b, cols) for pr, a, b, cols in recv if pr == peer]
             t = stack.new_empty((n * sum((b - a) * cols for a, b, cols in pieces),))
@@ -316,17 +327,64 @@ class ShardedFlow:
         ring[1] = (g + 1) % ring[0].shape[0]
         return ring[0][g], g, ring[2]
 
-    def stream_submit_own_rows(self, own_rows) -> int:
+    def stream_submit_own_rows(self, own_rows, overlap=None) -> int:
         """A tick's frames as this rank's own rows only ([n, rows, width] or a sequence): assemble (one exchange) and hand the
-        buffers to the stream pipeline in one call."""
+        buffers to the stream pipeline in one call.
+
+        overlap (default: on for device tensors when there is something to exchange): the exchange of THIS tick is enqueued on a
+        side stream and the launch of the tick BEFORE -- whose exchange has been running since the previous call -- on the caller's
+        stream, so that RCCL's sends and receives and the packing copies run underneath a tick's launches instead of between them.
+        One more tick of latency: the value returned is that of the tick submitted now (the previous call's frames), and
+        stream_drain() first flushes the tick still waiting.  Ordering: the side stream waits for everything enqueued on the
+        caller's stream so far -- the rows handed in, and the launches that last read the ring group this tick's buffers come
+        from (five groups, a borrowed frame is read for three ticks) --; the caller's stream waits for the exchange's event before
+        the launch that reads the assembled buffers."""
         from . import engine
 
         first = own_rows[0]
         bufs, g, groups = self._frame_buffers(len(own_rows), first)
-        self.assemble_frames(own_rows, bufs)
         if g not in groups:   # (the argument block of a ring group, packed once)
             groups[g] = engine.FrameGroup([bufs[i] for i in range(bufs.shape[0])])
-        return self.session.stream_submit_frames(groups[g])
+        if overlap is None:
+            import os
+
+            env = os.environ.get("OFX_SHARD_OVERLAP")   # (rehearsals on one rank: 1 forces the side stream on, 0 off)
+            overlap = (env == "1") if env in ("0", "1") else (bool(getattr(first, "is_cuda", False)) and self.world > 1)
+        if not overlap:
+            done = self._submit_pending()
+            self.assemble_frames(own_rows, bufs)
+            return max(done, self.session.stream_submit_frames(groups[g]))
+        import torch
+
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_xstream", None) is None:
+            self._xstream = torch.cuda.Stream()
+        x = self._xstream
+        x.wait_stream(cur)
+        with torch.cuda.stream(x):
+            self.assemble_frames(own_rows, bufs)
+            ev = torch.cuda.Event()
+            ev.record(x)
+        if hasattr(own_rows, "record_stream"):
+            own_rows.record_stream(x)   # (the caller may drop the tensor right away: its memory is in use on the side stream)
+        else:
+            for t in own_rows:
+                t.record_stream(x)
+        done = self._submit_pending()
+        self._pending = (groups[g], ev)
+        return done
+
+    def _submit_pending(self) -> int:
+        """the tick whose exchange was started by the previous stream_submit_own_rows(overlap=True), if any"""
+        pend = getattr(self, "_pending", None)
+        if pend is None:
+            return -1
+        import torch
+
+        self._pending = None
+        grp, ev = pend
+        torch.cuda.current_stream().wait_event(ev)
+        return self.session.stream_submit_frames(grp)
 
     def push_own_rows(self, rows):
         """pair-at-a-time form (the CPU stand-in of the tests): priming with this rank's own rows of the first frame"""

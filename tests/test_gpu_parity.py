@@ -636,6 +636,61 @@ def test_sharded_stream_sessions_read_only_their_rows_and_the_patch(eng, cfg):
             assert_same(full, want[p][k], f"{R} ranks, pair {p} level {k}")
 
 
+@pytest.mark.parametrize("iters", [1, 3])
+def test_own_rows_ticks_with_the_exchange_on_a_side_stream_equal_the_plain_sequence(eng, iters):
+    """ShardedFlow.stream_submit_own_rows(overlap=True): a tick's assembly (own rows -> ring buffers, the exchange) runs on a side
+    stream one tick ahead of the launch that reads it, events in between.  One rank has nothing to exchange, but the ordering is
+    the same: every pair of twelve ticks' worth of frames -- the ring of assembled buffers comes round more than twice -- must equal
+    the plain sequence bit for bit, with the returned pair numbers one tick late and stream_drain() flushing the waiting tick."""
+    import torch
+    from cuda_optical_flow_2_amd import parallel
+
+    w, h, L, win, B = 1280, 720, 4, 9, 2
+    nf = 12 * B
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.1 * i, -0.6 * i, seed=41)[1]).cuda() for i in range(nf)]
+    plain = eng.Session(w, h, L, win, "lk_float", iters=iters)
+    plain.set_frame_device(frames[0]); plain.build_pyramid(); plain.swap()
+    want = {}
+    for i in range(1, nf):
+        plain.set_frame_device(frames[i]); plain.build_pyramid(); plain.run_flow()
+        want[i] = [plain.flow(k)[0].clone() for k in range(L)]
+        plain.swap()
+    plain.close()
+    drv = parallel.ShardedFlow(w, h, L, win, "lk_float", 0, 1, device=0, corner="local", stream_batch=B, halo_mode="stream_exchange",
+                               borrow_frames=True, iters=iters)
+    s = drv.session
+    drv.stream_begin()
+    got, returned = {}, []
+
+    def snap(done):
+        for p in range(max(1, done - B + 1), done + 1):
+            if p not in got:
+                got[p] = [s.flow_of(p, k)[0].clone() for k in range(L)]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):   # (a caller's stream that is not the default one)
+        for t in range(nf // B):
+            rows = torch.stack(frames[t * B:(t + 1) * B])   # one rank: its own rows are the whole frame
+            done = drv.stream_submit_own_rows(rows, overlap=True)
+            del rows                                        # the driver must keep what its side stream still reads
+            returned.append(done)
+            if done >= 1:
+                snap(done)
+        while True:
+            done = drv.stream_drain()
+            if done == -2:
+                break
+            if done >= 1:
+                snap(done)
+    torch.cuda.synchronize()
+    assert returned[0] == -1 and returned[1] == -1, returned   # nothing is launched by the first call; the second launches tick 0
+    for p in range(1, nf):
+        for k in range(L):
+            a, b = got[p][k], want[p][k]
+            assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all().item()), (iters, p, k)
+    assert drv.corner_status() == 0
+    s.close()
+
+
 def test_local_corner_reports_a_shift_that_leaves_the_patch(eng):
     """ofx_session_corner_status must say exactly when a corner shift needed pixels the patch does not hold.  Pixel 0's
     flow is normally tiny (the zero border dominates its gradients), so the frames are a dark-cornered ramp whose
