@@ -512,6 +512,217 @@ __global__ __launch_bounds__(256) void bilateral_fast_sep_kernel(const uint8_t *
     d[2] = (uint8_t)(int)a2;
 }
 
+// ---- the same +-1 LSB filter with the range weight LOOKED UP in an LDS table (round 4) ------------------------
+// bilateral_fast_sep_kernel pays, per tap, six vector instructions of which one is a transcendental (10.1 ns per tap and wave,
+// tools/ubench/lds_rates.hip "tap: exponential").  The range weight only depends on the integer |d| = |g_q - g_0|, so a table per
+// window column n -- tab[n][i] = a_n * range(i), i = |d| -- turns the tap into: v_sub_f32 (d4 = 4 g_q - 4 g_0: the tile holds 4 g as
+// floats, so that ...), v_cvt_u32_f32 |d4| (... the conversion IS the byte offset into the table), ds_read_b32 with the column's
+// offset as the instruction's immediate, v_add_f32, v_fma_f32: four vector instructions, none of them slow, and one LDS read.
+// (ds_bpermute_b32 out of a table held across the lanes was measured first: 10 ns per permute and SIMD, slower than the
+// exponential it replaces -- profiles/r04_ablation.txt batch 9.)  An out-of-image tap is stored as 4 * -256, which puts its |d| at
+// 256 ... 511: the table's upper half, all zeros -- no compare, no clamp.  A lane owns a 2 x 2 block of pixels: a tile row's ten
+// values arrive as five 8-byte LDS reads and serve the taps of both of its rows.  The tile is loaded four pixels = three dwords at a
+// time.  For what main.cu:240 filters: the grey image as its own source (src == gray, one pointer), every channel equal -- checked
+// per tile while loading; a tile that fails takes a slow pixel-by-pixel path, still within the tolerance.  No condition on sigma_b:
+// the table covers every |d| a byte image has.
+constexpr int kLutTileW = 128, kLutTileH = 32, kLutEntries = 512, kLutThreads = 512; // (eight waves share one table and one halo)
+constexpr float kLutOutside = -1024.0f; // 4 * -256
+struct BilateralLutArg {
+    float row[kMaxBilateral];      // a_m (= a_n: the mask is symmetric)
+    float log2_col[kMaxBilateral]; // log2 a_n (tiles with colour)
+    float c;                       // -log2(e) / (2 sigma_b^2)
+    float range[kLutEntries];      // exp2(c * i * i), zero from 256 on
+};
+
+// The LDS serves one lookup per ~2 clocks and CU plus what the bank conflicts of a wave's 64 addresses cost (1.6 ... 4 clocks more
+// by the image's content, SQ_LDS_BANK_CONFLICT), and that is the kernel's bound; the vector memory path idles meanwhile.  So some
+// window columns take range(|d|) out of the kernel-argument block instead -- the same byte offset, a gather the L1 serves out of one
+// or two cache lines for the |d| that matter -- at one more multiplication per tap (a_n is not folded into that table).
+// A third engine is the transcendental unit: a column can also compute its weight (v_exp_f32, two more instructions).
+// SPLIT = 10 * columns through memory (columns 1, 5) + columns computed (columns 3, 7, 0, WW - 1).  Measured on a 4K frame, 9 x 9
+// (profiles/r04_ablation.txt batch 9): all LDS 108 us; two through memory 100; three 130 (the gather costs the texture path more
+// than the LDS); two computed 95; one through memory + two computed 92-94 -- the default; more of either is slower again.
+// OFX_LUT_SPLIT selects 0, 2, 10 or 12 at run time for the A/B.
+#ifndef OFX_LUT_SPLIT_DEFAULT
+#define OFX_LUT_SPLIT_DEFAULT 12
+#endif
+__device__ __host__ constexpr bool lut_column_in_memory(int n, int ww, int split) { return ww >= 7 && ((split / 10 >= 1 && n == 1) || (split / 10 >= 2 && n == 5)); }
+__device__ __host__ constexpr bool lut_column_computed(int n, int ww, int split)
+{
+    return ww >= 7 && ((split % 10 >= 1 && n == 3) || (split % 10 >= 2 && n == 7 % ww) || (split % 10 >= 3 && n == 0) || (split % 10 >= 4 && n == ww - 1 && ww > 7));
+}
+
+// the taps of one tile row for the lane's two pixels of one output row: v = the WW + 1 tile values, g = the two centre values
+template <int WW, int EVERY>
+__device__ __forceinline__ void lut_row_taps(const float (&v)[WW + 1], float gA, float gB, const char *tabb, float am, float (&acc)[4], const BilateralLutArg &B)
+{
+    const char *rangeb = reinterpret_cast<const char *>(B.range);
+    float wsA = 0.0f, asA = 0.0f, wsB = 0.0f, asB = 0.0f;
+#pragma unroll
+    for (int n = 0; n < WW; ++n) {
+        const float dA = v[n] - gA, dB = v[n + 1] - gB; // exact: multiples of 4 below 2^12
+        const uint32_t iA = (uint32_t)__builtin_fabsf(dA), iB = (uint32_t)__builtin_fabsf(dB); // = 4 |d|: the entry's byte offset
+        if (lut_column_in_memory(n, WW, EVERY)) { // range(|d|) out of the kernel-argument block through the vector memory path; a_n applied here
+            const float rA = *reinterpret_cast<const float *>(rangeb + iA), rB = *reinterpret_cast<const float *>(rangeb + iB);
+            const float an = B.row[n];
+            wsA = __builtin_fmaf(an, rA, wsA);
+            asA = __builtin_fmaf(dA * an, rA, asA);
+            wsB = __builtin_fmaf(an, rB, wsB);
+            asB = __builtin_fmaf(dB * an, rB, asB);
+        } else if (lut_column_computed(n, WW, EVERY)) { // (an out-of-image tap: d4 = -1024 - 4 g_0, the exponent far below the underflow for any sigma_b the entry accepts)
+            const float wA = __builtin_amdgcn_exp2f(__builtin_fmaf(dA * dA, 0.0625f * B.c, B.log2_col[n]));
+            const float wB = __builtin_amdgcn_exp2f(__builtin_fmaf(dB * dB, 0.0625f * B.c, B.log2_col[n]));
+            wsA += wA;
+            asA = __builtin_fmaf(dA, wA, asA);
+            wsB += wB;
+            asB = __builtin_fmaf(dB, wB, asB);
+        } else {
+            const float wA = *reinterpret_cast<const float *>(tabb + n * (kLutEntries * 4) + iA);
+            const float wB = *reinterpret_cast<const float *>(tabb + n * (kLutEntries * 4) + iB);
+            wsA += wA;
+            asA = __builtin_fmaf(dA, wA, asA);
+            wsB += wB;
+            asB = __builtin_fmaf(dB, wB, asB);
+        }
+    }
+    acc[0] = __builtin_fmaf(am, wsA, acc[0]);
+    acc[1] = __builtin_fmaf(am, asA, acc[1]);
+    acc[2] = __builtin_fmaf(am, wsB, acc[2]);
+    acc[3] = __builtin_fmaf(am, asB, acc[3]);
+}
+
+template <int WW, int EVERY>
+__global__ __launch_bounds__(kLutThreads) void bilateral_lut_kernel(const uint8_t *img3, uint8_t *dst3, int w, int h, const BilateralLutArg B)
+{
+    constexpr int R = WW >> 1, TW = kLutTileW + 2 * R, NG = (TW + 3) / 4, TWP = NG * 4, ROWS = kLutTileH + 2 * R;
+    __shared__ __attribute__((aligned(16))) float g4[ROWS * TWP]; // 4 * grey value, or kLutOutside
+    __shared__ __attribute__((aligned(16))) float tab[WW * kLutEntries];
+    const int tid = (int)threadIdx.x, x0 = (int)blockIdx.x * kLutTileW, y0 = (int)blockIdx.y * kLutTileH;
+    const int bytes = 3 * w * h; // (below 2 GB: launch_bilateral_lut)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img3), 0, bytes, 0x00027000);
+    uint32_t colour = 0u;
+    for (int i = tid; i < ROWS * NG; i += kLutThreads) {
+        const int gr = i / NG, gc = i - gr * NG, ty = y0 - R + gr, tx = x0 - R + 4 * gc;
+        float g[4] = {kLutOutside, kLutOutside, kLutOutside, kLutOutside};
+        if (ty >= 0 && ty < h && tx + 3 >= 0 && tx < w) {
+            const int off = 3 * (ty * w + tx);
+            if (off >= 0 && off + 12 <= bytes) { // twelve bytes = four pixels in three dwords (a pixel left of column 0 is the end of the row above)
+                const uint32_t a = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4, 0, 0),
+                               c = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 8, 0, 0);
+                // what the dwords would hold with every channel equal to channel 0 (of pixels that are real pixels, in the image or a row off)
+                colour |= (a ^ __builtin_amdgcn_perm(a, a, 0x03000000u)) | (b ^ __builtin_amdgcn_perm(b, a, 0x06060303u)) |
+                          (c ^ __builtin_amdgcn_perm(c, b, 0x05050502u));
+                const float v[4] = {(float)(a & 0xffu), (float)(a >> 24), (float)((b >> 16) & 0xffu), (float)((c >> 8) & 0xffu)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (tx + k >= 0 && tx + k < w) g[k] = 4.0f * v[k];
+            } else { // the image's first and last bytes
+                for (int k = 0; k < 4; ++k)
+                    if (tx + k >= 0 && tx + k < w) {
+                        const uint8_t *q = img3 + 3 * ((size_t)ty * w + tx + k);
+                        colour |= (uint32_t)(q[0] ^ q[1]) | (uint32_t)(q[0] ^ q[2]);
+                        g[k] = 4.0f * (float)q[0];
+                    }
+            }
+        }
+        *reinterpret_cast<float4 *>(g4 + gr * TWP + 4 * gc) = float4{g[0], g[1], g[2], g[3]};
+    }
+    {
+        const float rg = tid < 256 ? B.range[tid] : 0.0f; // 512 threads: one entry each, times every column's a_n
+#pragma unroll
+        for (int n = 0; n < WW; ++n) tab[n * kLutEntries + tid] = B.row[n] * rg;
+    }
+    const int grey = __syncthreads_and(colour == 0u ? 1 : 0);
+    const int lane = tid & 63, wv = tid >> 6;
+    if (!grey) { // a tile whose channels differ: the exponential, pixel by pixel, the channels out of global memory
+        for (int t = 0; t < 8; ++t) {
+            const int lx = 2 * lane + (t & 1), ly = 4 * wv + (t >> 1), x = x0 + lx, y = y0 + ly;
+            if (x >= w || y >= h) continue;
+            const float g0 = 0.25f * g4[(ly + R) * TWP + lx + R];
+            float wsum = 0.0f, a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+            for (int m = 0; m < WW; ++m) {
+                float ws = 0.0f, r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+                for (int n = 0; n < WW; ++n) {
+                    const float gq = g4[(ly + m) * TWP + lx + n];
+                    if (gq < 0.0f) continue; // outside the image
+                    const float d = 0.25f * gq - g0;
+                    const float wgt = __builtin_amdgcn_exp2f(__builtin_fmaf(d * d, B.c, B.log2_col[n]));
+                    const uint8_t *q = img3 + 3 * ((size_t)(y - R + m) * w + (x - R + n));
+                    ws += wgt;
+                    r0 = __builtin_fmaf((float)q[0], wgt, r0);
+                    r1 = __builtin_fmaf((float)q[1], wgt, r1);
+                    r2 = __builtin_fmaf((float)q[2], wgt, r2);
+                }
+                wsum = __builtin_fmaf(B.row[m], ws, wsum);
+                a0 = __builtin_fmaf(B.row[m], r0, a0);
+                a1 = __builtin_fmaf(B.row[m], r1, a1);
+                a2 = __builtin_fmaf(B.row[m], r2, a2);
+            }
+            uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+            d[0] = (uint8_t)(int)(a0 / wsum);
+            d[1] = (uint8_t)(int)(a1 / wsum);
+            d[2] = (uint8_t)(int)(a2 / wsum);
+        }
+        return;
+    }
+    const char *tabb = reinterpret_cast<const char *>(tab);
+#pragma unroll 1
+    for (int pr = 0; pr < 2; ++pr) {
+        const int ly = 4 * wv + 2 * pr; // output rows ly, ly + 1 of the tile
+        const float2 c0 = *reinterpret_cast<const float2 *>(g4 + (ly + R) * TWP + 2 * lane + R - (R & 1)),
+                     c0b = *reinterpret_cast<const float2 *>(g4 + (ly + R) * TWP + 2 * lane + R + (R & 1)),
+                     c1 = *reinterpret_cast<const float2 *>(g4 + (ly + 1 + R) * TWP + 2 * lane + R - (R & 1)),
+                     c1b = *reinterpret_cast<const float2 *>(g4 + (ly + 1 + R) * TWP + 2 * lane + R + (R & 1));
+        const float g00 = (R & 1) ? c0.y : c0.x, g01 = (R & 1) ? c0b.x : c0.y, g10 = (R & 1) ? c1.y : c1.x, g11 = (R & 1) ? c1b.x : c1.y;
+        float acc0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, acc1[4] = {0.0f, 0.0f, 0.0f, 0.0f}; // per output row: wsum A, a A, wsum B, a B
+#pragma unroll 1
+        for (int t = 0; t <= WW; ++t) { // tile row ly + t: tap row t of output row ly, tap row t - 1 of output row ly + 1
+            const float2 *grow = reinterpret_cast<const float2 *>(g4 + (ly + t) * TWP + 2 * lane); // (TWP and 2 * lane are even: 8-byte aligned)
+            float v[WW + 1];
+#pragma unroll
+            for (int k = 0; k < (WW + 1) / 2; ++k) {
+                const float2 q = grow[k];
+                v[2 * k] = q.x;
+                v[2 * k + 1] = q.y;
+            }
+            if (t < WW) lut_row_taps<WW, EVERY>(v, g00, g01, tabb, B.row[t < WW ? t : 0], acc0, B);
+            if (t > 0) lut_row_taps<WW, EVERY>(v, g10, g11, tabb, B.row[t > 0 ? t - 1 : 0], acc1, B);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + ly + r, xA = x0 + 2 * lane;
+            if (y >= h || xA >= w) continue;
+            const float(&acc)[4] = r ? acc1 : acc0;
+            const float gA = r ? g10 : g00, gB = r ? g11 : g01;
+            const uint32_t bA = (uint32_t)(int)(0.25f * (gA + acc[1] / acc[0])), bB = (uint32_t)(int)(0.25f * (gB + acc[3] / acc[2])); // g_0 + sum d w / sum w
+            uint8_t *d = dst3 + 3 * ((size_t)y * w + xA);
+            if (xA + 1 < w) {
+                uint16_t *d2 = reinterpret_cast<uint16_t *>(d); // (two-byte stores at any byte address: unaligned access is on for global memory)
+                d2[0] = (uint16_t)(bA * 0x0101u), d2[1] = (uint16_t)(bA | (bB << 8)), d2[2] = (uint16_t)(bB * 0x0101u);
+            } else {
+                d[0] = (uint8_t)bA, d[1] = (uint8_t)bA, d[2] = (uint8_t)bA;
+            }
+        }
+    }
+}
+
+template <int WW>
+int launch_bilateral_lut(const uint8_t *d_img3, uint8_t *d_dst3, int w, int h, const BilateralLutArg &B, hipStream_t st)
+{
+    static const int split = [] { const char *e = getenv("OFX_LUT_SPLIT"); return e ? atoi(e) : OFX_LUT_SPLIT_DEFAULT; }();
+    // (a computed column gives an out-of-image tap, 256 grey levels or more away, its zero weight by underflow: sigma_b <= ~17)
+    const int use = (double)B.c * 65536.0 <= -150.0 ? split : split / 10 * 10;
+    const dim3 grid(ofx_div_up(w, kLutTileW), ofx_div_up(h, kLutTileH));
+#define OFX_LUT_CASE(S) case S: hipLaunchKernelGGL((bilateral_lut_kernel<WW, S>), grid, dim3(kLutThreads), 0, st, d_img3, d_dst3, w, h, B); break;
+    switch (use) {
+        OFX_LUT_CASE(0) OFX_LUT_CASE(2) OFX_LUT_CASE(10)
+    default: hipLaunchKernelGGL((bilateral_lut_kernel<WW, 12>), grid, dim3(kLutThreads), 0, st, d_img3, d_dst3, w, h, B); break;
+    }
+#undef OFX_LUT_CASE
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 template <int WW>
 int launch_bilateral_fast_sep(const uint8_t *d_src3, const uint8_t *d_gray3, uint8_t *d_dst3, int w, int h, const BilateralSepArg &B, hipStream_t st)
 {
@@ -899,6 +1110,26 @@ extern "C" int ofx_bilateral_3ch_fast(const uint8_t *d_src3, const uint8_t *d_gr
                 S.log2_col[n] = (float)log2(sp[c * ww + n] / root);
             }
             S.c = B.c;
+            // the grey image as its own source (main.cu:240): the range weight out of an LDS table instead of the exponential
+            // (OFX_BILATERAL_LUT=0: always the exponential)
+            static const bool lut_on = [] { const char *e = getenv("OFX_BILATERAL_LUT"); return !e || atoi(e) != 0; }();
+            if (lut_on && d_src3 == d_gray3 && 3ll * w * h + 16 < (1ll << 31)) {
+                static thread_local BilateralLutArg T;
+                for (int n = 0; n < ww; ++n) {
+                    T.row[n] = S.row[n];
+                    T.log2_col[n] = S.log2_col[n];
+                }
+                for (int i = 0; i < kLutEntries; ++i) T.range[i] = i < 256 ? (float)exp2((double)B.c * i * i) : 0.0f;
+                T.c = B.c;
+                switch (ww) {
+                case 3: return launch_bilateral_lut<3>(d_gray3, d_dst3, w, h, T, st);
+                case 5: return launch_bilateral_lut<5>(d_gray3, d_dst3, w, h, T, st);
+                case 7: return launch_bilateral_lut<7>(d_gray3, d_dst3, w, h, T, st);
+                case 9: return launch_bilateral_lut<9>(d_gray3, d_dst3, w, h, T, st);
+                case 11: return launch_bilateral_lut<11>(d_gray3, d_dst3, w, h, T, st);
+                default: return launch_bilateral_lut<13>(d_gray3, d_dst3, w, h, T, st);
+                }
+            }
             switch (ww) {
             case 3: return launch_bilateral_fast_sep<3>(d_src3, d_gray3, d_dst3, w, h, S, st);
             case 5: return launch_bilateral_fast_sep<5>(d_src3, d_gray3, d_dst3, w, h, S, st);

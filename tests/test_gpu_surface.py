@@ -227,6 +227,83 @@ def test_fast_bilateral_filter_is_within_one_lsb(gpu, cpu, oracle, golden, size)
     assert_same(gpu.bilinear_filter(grey, grey, 9, 9, 2.0, 10.0), oracle.bilateral_3ch(grey, grey, 9, 9, 2.0, 10.0), "exact again")
 
 
+@pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (3, 1), (130, 131), (261, 35)])
+def test_fast_bilateral_filter_with_the_range_table_is_within_one_lsb(oracle, size):
+    """The grey image as its own source (one device pointer for src and gray, main.cu:240) takes bilateral_lut_kernel: range weights
+    out of an LDS table indexed by |d|, a 2 x 2 pixel block per lane, the tile loaded three dwords = four pixels at a time.  Every
+    odd square window up to 13, sizes that are not multiples of the 128 x 16 tile or of four pixels (the byte path at the image's
+    first and last bytes), a wide range Gaussian (no clamp at |d| = 63 or anywhere), and an image whose channels differ under
+    that one pointer (the tile-wise check sends it down the exponential path): within +-1 of the oracle's bit-exact filter."""
+    import torch
+
+    from cuda_optical_flow_2_amd import lib
+
+    L = lib.load()
+    w, h = size
+    rng = np.random.default_rng(w * 77 + h)
+    noise = oracle.grayscale_avg(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    smooth = synth.to_3ch(synth.smooth_pair(max(w, 8), max(h, 8), 0, 0, seed=9)[1])[:h, :w].copy()
+    colour = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    half = smooth.copy()
+    half[:, w // 2:, 1] ^= 0x10  # grey tiles and tiles with colour in one image
+    st = torch.cuda.current_stream().cuda_stream
+    for (ww, ss, sb) in ((3, 0.8, 10.0), (5, 1.5, 20.0), (7, 1.0, 5.0), (9, 2.0, 10.0), (11, 2.5, 3.0), (13, 3.0, 40.0), (9, 2.0, 400.0), (9, 2.0, 1.5)):
+        for img, what in ((noise, "noise"), (smooth, "smooth"), (colour, "colour"), (half, "half colour")):
+            d_img = torch.from_numpy(img).cuda()
+            d_out = torch.full_like(d_img, 0x5a)
+            lib.check(L.ofx_bilateral_3ch_fast(d_img.data_ptr(), d_img.data_ptr(), d_out.data_ptr(), w, h, ww, ww, ss, sb, st), "fast")
+            got = d_out.cpu().numpy().astype(np.int32)
+            want = oracle.bilateral_3ch(img, img, ww, ww, ss, sb).astype(np.int32)
+            d = np.abs(got - want)
+            assert d.max() <= 1, f"{what} {ww}x{ww} sigma_b {sb} at {w}x{h}: off by {d.max()} at {np.argwhere(d > 1)[:4].tolist()}"
+
+
+_SPLIT_SNIPPET = """
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch
+from cuda_optical_flow_2_amd import lib, synth
+L = lib.load()
+st = torch.cuda.current_stream().cuda_stream
+out = {{}}
+for (w, h) in ((261, 35), (130, 131)):
+    rng = np.random.default_rng(w)
+    noise = np.repeat(rng.integers(0, 256, (h, w, 1), dtype=np.uint8), 3, axis=2)
+    smooth = synth.to_3ch(synth.smooth_pair(w, h, 0, 0, seed=9)[1])
+    for (ww, ss, sb) in ((7, 1.0, 5.0), (9, 2.0, 10.0), (13, 3.0, 40.0)):
+        for name, img in (("noise", noise), ("smooth", smooth)):
+            d_img = torch.from_numpy(img).cuda()
+            d_out = torch.empty_like(d_img)
+            lib.check(L.ofx_bilateral_3ch_fast(d_img.data_ptr(), d_img.data_ptr(), d_out.data_ptr(), w, h, ww, ww, ss, sb, st), "fast")
+            out[f"{{w}}x{{h}}_{{ww}}_{{name}}"] = d_out.cpu().numpy()
+np.savez(sys.argv[1], **out)
+print("split ok")
+"""
+
+
+def test_fast_bilateral_filter_is_the_same_filter_however_its_columns_are_split(tmp_path):
+    """bilateral_lut_kernel spreads a window's columns over three engines (LDS table, a gather out of the kernel-argument block,
+    v_exp_f32); OFX_LUT_SPLIT picks the split per process.  Child processes with every split the library carries (0: all LDS,
+    2: two computed, 10: one gathered, 12: the default) filter the same images; the outputs may differ from the default's by the
+    rounding of a weight, never by more than one grey level -- the default is the one pinned to the oracle above."""
+    import os
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for split in ("12", "0", "2", "10"):
+        path = str(tmp_path / f"split{split}.npz")
+        r = subprocess.run([_sys.executable, "-c", _SPLIT_SNIPPET.format(root=root), path], env=dict(os.environ, OFX_LUT_SPLIT=split),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "split ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+        got[split] = dict(np.load(path))
+    for split in ("0", "2", "10"):
+        for k, v in got["12"].items():
+            d = np.abs(got[split][k].astype(np.int32) - v.astype(np.int32))
+            assert d.max() <= 1, f"split {split}, {k}: off by {d.max()}"
+
+
 @pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (130, 131)])
 def test_bilateral_filter_tiled_kernel_matches_oracle(gpu, cpu, oracle, size):
     """The tiled bilateral kernel (LDS neighbourhood, range table by signed difference, out-of-image taps as +0.0) is the

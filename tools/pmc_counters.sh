@@ -1,5 +1,6 @@
 # SQ counters of one kernel for one configuration, separate rocprofv3 --pmc passes (no tracing alongside):
 #   bash tools/pmc_counters.sh <out dir under gpurun_out> <kernel substring> <pmc_run.py args...>
+#   PMC_PROG=tools/bil_bench.py PMC_LDS=1 bash tools/pmc_counters.sh ...   another program under the counters; the LDS counters too
 # prints, per counter, the mean over the launches of that kernel (first 3 skipped)
 set -e
 cd /tmp && export TMPDIR=/tmp
@@ -7,9 +8,12 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1; K=$2; shift 2
 rm -rf $O; mkdir -p $O
 cd $R
-for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+PROG=${PMC_PROG:-tools/pmc_run.py}
+EXTRA=()
+if [ -n "$PMC_LDS" ]; then EXTRA=("SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"); fi
+for C in "${EXTRA[@]}" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python tools/pmc_run.py "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
+  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python $PROG "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
 done
 python - "$O" "$K" <<'PY'
 import csv, glob, os, sys
