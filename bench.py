@@ -873,7 +873,8 @@ class Run:
             fe[nm] = {"grayscale_us": round(t_g, 1), "grayscale_frac": round(6 * wa * ha / (t_g * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                       "bilateral_9x9_us": round(t_b, 1), "bilateral_frac": round(9 * wa * ha / (t_b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                       "bilateral_9x9_fast_us": round(t_f, 1), "bilateral_fast_frac": round(9 * wa * ha / (t_f * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                      "bilateral_fast": "ofx_bilateral_3ch_fast: within +-1 LSB of the bit-exact kernel (SURVEY 8c's tolerance for this stage), opt-in",
+                      "bilateral_fast": "ofx_bilateral_3ch_fast: within +-1 LSB of the bit-exact kernel (SURVEY 8c's tolerance for this stage), opt-in; "
+                                        "both are called as main.cu:240 calls them (the grey image as src and gray: the own-image kernels, DESIGN 4.6)",
                       "value": round(wa * ha / ((t_g + t_b) * 1e-6) / 1e6, 1), "unit": "Mpix/s",
                       "value_fast_bilateral": round(wa * ha / ((t_g + t_f) * 1e-6) / 1e6, 1)}
             del img, gray, filt

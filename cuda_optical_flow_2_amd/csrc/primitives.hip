@@ -339,6 +339,144 @@ __global__ __launch_bounds__(256) void bilateral_tiled_kernel(const uint8_t *src
     d[2] = (uint8_t)(int)(a2 / wsum);
 }
 
+// ---- the bit-exact filter of an image that is its own grey image (main.cu:240: src == gray, one pointer), round 4 -----------------
+// bilateral_tiled_kernel reads the LDS three times per tap (the source pixel, the grey offset, the 8-byte table entry) for its
+// seven double-precision operations, and the LDS is what bounds it.  With src == gray and every channel equal -- checked per tile while
+// loading -- the pixel value IS the grey value: the tile holds one int per pixel, a lane owns a 2 x 2 block of pixels and reads a
+// tile row's WW + 1 values as 8-byte pieces that serve both of its output rows, and the tap is v_lshl_add_u32 (the table address),
+// ds_read_b64 (nb), v_cvt_f64_u32, and the reference's five double operations in the reference's order (wsum += nb * ns;
+// a += ((double)px * nb) * ns, row-major over the window: OptFlowCPU.cpp:437-452): 1.1 LDS reads per tap instead of 3.
+// Out-of-image taps: the sentinel grey value's table entries are +0.0, additions of +0.0 to these non-negative sums are exact no-ops
+// (as in bilateral_tiled_kernel).  A tile whose channels differ takes a slow pixel-by-pixel path with the channels out of global memory.
+constexpr int kExTileW = 128, kExTileH = 32, kExThreads = 512;
+
+template <int WW>
+__device__ __forceinline__ void exact_row_taps(const int (&v)[WW + 1], int baseA, int baseB, const uint8_t *lut_b, const double *ns, double (&acc)[4])
+{
+#pragma unroll
+    for (int n = 0; n < WW; ++n) {
+        const double nbA = *reinterpret_cast<const double *>(lut_b + (8 * v[n] + baseA)), nbB = *reinterpret_cast<const double *>(lut_b + (8 * v[n + 1] + baseB));
+        const double s = ns[n];
+        acc[0] += nbA * s;
+        acc[1] += (double)(uint32_t)v[n] * nbA * s;
+        acc[2] += nbB * s;
+        acc[3] += (double)(uint32_t)v[n + 1] * nbB * s;
+    }
+}
+
+template <int WW>
+__global__ __launch_bounds__(kExThreads) void bilateral_exact_own_kernel(const uint8_t *img3, uint8_t *dst3, int w, int h, const BilateralArg B)
+{
+    constexpr int R = WW >> 1, TW = kExTileW + 2 * R, NG = (TW + 3) / 4, TWP = NG * 4, ROWS = kExTileH + 2 * R;
+    __shared__ __attribute__((aligned(16))) double lut[kBilLut];
+    __shared__ __attribute__((aligned(16))) int gt[ROWS * TWP]; // grey value, or kBilSentinel
+    const int tid = (int)threadIdx.x, x0 = (int)blockIdx.x * kExTileW, y0 = (int)blockIdx.y * kExTileH;
+    const int bytes = 3 * w * h; // (below 2 GB: the launcher)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(img3), 0, bytes, 0x00027000);
+    for (int i = tid; i < kBilLut; i += kExThreads) {
+        const int d = i - 255; // signed grey difference
+        lut[i] = (d >= -255 && d <= 255) ? B.range[d < 0 ? -d : d] : 0.0;
+    }
+    uint32_t colour = 0u;
+    for (int i = tid; i < ROWS * NG; i += kExThreads) {
+        const int gr = i / NG, gc = i - gr * NG, ty = y0 - R + gr, tx = x0 - R + 4 * gc;
+        int g[4] = {kBilSentinel, kBilSentinel, kBilSentinel, kBilSentinel};
+        if (ty >= 0 && ty < h && tx + 3 >= 0 && tx < w) {
+            const int off = 3 * (ty * w + tx);
+            if (off >= 0 && off + 12 <= bytes) { // twelve bytes = four pixels in three dwords (as bilateral_lut_kernel)
+                const uint32_t a = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4, 0, 0),
+                               c = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 8, 0, 0);
+                colour |= (a ^ __builtin_amdgcn_perm(a, a, 0x03000000u)) | (b ^ __builtin_amdgcn_perm(b, a, 0x06060303u)) |
+                          (c ^ __builtin_amdgcn_perm(c, b, 0x05050502u));
+                const int v[4] = {(int)(a & 0xffu), (int)(a >> 24), (int)((b >> 16) & 0xffu), (int)((c >> 8) & 0xffu)};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (tx + k >= 0 && tx + k < w) g[k] = v[k];
+            } else {
+                for (int k = 0; k < 4; ++k)
+                    if (tx + k >= 0 && tx + k < w) {
+                        const uint8_t *q = img3 + 3 * ((size_t)ty * w + tx + k);
+                        colour |= (uint32_t)(q[0] ^ q[1]) | (uint32_t)(q[0] ^ q[2]);
+                        g[k] = (int)q[0];
+                    }
+            }
+        }
+        *reinterpret_cast<int4 *>(gt + gr * TWP + 4 * gc) = int4{g[0], g[1], g[2], g[3]};
+    }
+    const int grey = __syncthreads_and(colour == 0u ? 1 : 0);
+    const int lane = tid & 63, wv = tid >> 6;
+    const uint8_t *lut_b = reinterpret_cast<const uint8_t *>(lut);
+    if (!grey) { // channels differ: pixel by pixel, the channels out of global memory, the reference's order
+        for (int t = 0; t < 8; ++t) {
+            const int lx = 2 * lane + (t & 1), ly = 4 * wv + (t >> 1), x = x0 + lx, y = y0 + ly;
+            if (x >= w || y >= h) continue;
+            const int g0 = gt[(ly + R) * TWP + lx + R];
+            double wsum = 0.0, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int m = 0; m < WW; ++m)
+                for (int n = 0; n < WW; ++n) {
+                    const int gq = gt[(ly + m) * TWP + lx + n];
+                    if (gq == kBilSentinel) continue; // outside the image (OptFlowCPU.cpp:432 skips the tap)
+                    const double nb = lut[gq - g0 + 255], ns = B.spatial[m * WW + n];
+                    const uint8_t *q = img3 + 3 * ((size_t)(y - R + m) * w + (x - R + n));
+                    wsum += nb * ns;
+                    a0 += (double)q[0] * nb * ns;
+                    a1 += (double)q[1] * nb * ns;
+                    a2 += (double)q[2] * nb * ns;
+                }
+            uint8_t *d = dst3 + 3 * ((size_t)y * w + x);
+            d[0] = (uint8_t)(int)(a0 / wsum);
+            d[1] = (uint8_t)(int)(a1 / wsum);
+            d[2] = (uint8_t)(int)(a2 / wsum);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int pr = 0; pr < 2; ++pr) {
+        const int ly = 4 * wv + 2 * pr; // output rows ly, ly + 1 of the tile
+        const int g00 = gt[(ly + R) * TWP + 2 * lane + R], g01 = gt[(ly + R) * TWP + 2 * lane + 1 + R], g10 = gt[(ly + 1 + R) * TWP + 2 * lane + R],
+                  g11 = gt[(ly + 1 + R) * TWP + 2 * lane + 1 + R];
+        // byte offset of table entry (g - g_0 + 255) = 8 g + base
+        const int b00 = 8 * (255 - g00), b01 = 8 * (255 - g01), b10 = 8 * (255 - g10), b11 = 8 * (255 - g11);
+        double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0}; // per output row: wsum A, a A, wsum B, a B
+#pragma unroll 1
+        for (int t = 0; t <= WW; ++t) { // tile row ly + t: tap row t of output row ly, tap row t - 1 of output row ly + 1
+            const int2 *grow = reinterpret_cast<const int2 *>(gt + (ly + t) * TWP + 2 * lane);
+            int v[WW + 1];
+#pragma unroll
+            for (int k = 0; k < (WW + 1) / 2; ++k) {
+                const int2 q = grow[k];
+                v[2 * k] = q.x;
+                v[2 * k + 1] = q.y;
+            }
+            if (t < WW) exact_row_taps<WW>(v, b00, b01, lut_b, B.spatial + (t < WW ? t : 0) * WW, acc0);
+            if (t > 0) exact_row_taps<WW>(v, b10, b11, lut_b, B.spatial + (t > 0 ? t - 1 : 0) * WW, acc1);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + ly + r, xA = x0 + 2 * lane;
+            if (y >= h || xA >= w) continue;
+            const double(&acc)[4] = r ? acc1 : acc0;
+            const uint32_t bA = (uint32_t)(uint8_t)(int)(acc[1] / acc[0]), bB = (uint32_t)(uint8_t)(int)(acc[3] / acc[2]);
+            uint8_t *d = dst3 + 3 * ((size_t)y * w + xA);
+            if (xA + 1 < w) {
+                uint16_t *d2 = reinterpret_cast<uint16_t *>(d);
+                d2[0] = (uint16_t)(bA * 0x0101u), d2[1] = (uint16_t)(bA | (bB << 8)), d2[2] = (uint16_t)(bB * 0x0101u);
+            } else {
+                d[0] = (uint8_t)bA, d[1] = (uint8_t)bA, d[2] = (uint8_t)bA;
+            }
+        }
+    }
+}
+
+template <int WW>
+int launch_bilateral_exact_own(const uint8_t *d_img3, uint8_t *d_dst3, int w, int h, const BilateralArg &B, hipStream_t st)
+{
+    hipLaunchKernelGGL(bilateral_exact_own_kernel<WW>, dim3(ofx_div_up(w, kExTileW), ofx_div_up(h, kExTileH)), dim3(kExThreads), 0, st, d_img3, d_dst3, w,
+                       h, B);
+    OFX_HIP(hipGetLastError());
+    return OFX_OK;
+}
+
 // ---- the same filter within SURVEY 8c's tolerance for this stage (+-1 LSB), opt-in ---------------------------------------------
 // The exact kernel above is bound by its definition: 81 taps x 7-15 double-precision operations per pixel in the reference's
 // order, each weight an 8-byte LDS gather.  This one keeps the filter and drops the order: float accumulators, the range weight
@@ -1165,6 +1303,19 @@ extern "C" int ofx_bilateral_3ch(const uint8_t *d_src3, const uint8_t *d_gray3, 
         B.range[k] = 1.0 / (2.0 * M_PI * sb2) * pow(M_E, -0.5 * (kk) / sb2);
     }
     hipStream_t st = ofx_stream(stream);
+    // the image as its own grey image, square window (main.cu:240): one LDS read per tap (OFX_BILATERAL_OWN=0: the general kernel)
+    static const bool own_on = [] { const char *e = getenv("OFX_BILATERAL_OWN"); return !e || atoi(e) != 0; }();
+    if (own_on && d_src3 == d_gray3 && wh == ww && 3ll * w * h + 16 < (1ll << 31)) {
+        switch (ww) {
+        case 3: return launch_bilateral_exact_own<3>(d_gray3, d_dst3, w, h, B, st);
+        case 5: return launch_bilateral_exact_own<5>(d_gray3, d_dst3, w, h, B, st);
+        case 7: return launch_bilateral_exact_own<7>(d_gray3, d_dst3, w, h, B, st);
+        case 9: return launch_bilateral_exact_own<9>(d_gray3, d_dst3, w, h, B, st);
+        case 11: return launch_bilateral_exact_own<11>(d_gray3, d_dst3, w, h, B, st);
+        case 13: return launch_bilateral_exact_own<13>(d_gray3, d_dst3, w, h, B, st);
+        default: break;
+        }
+    }
     if (wh == ww || (wh & 1)) { // (the tiled kernel centres the rows on wh / 2 like the reference; any wh <= ww works)
         switch (ww) {
         case 3: return launch_bilateral_tiled<3>(d_src3, d_gray3, d_dst3, w, h, wh, B, st);

@@ -258,6 +258,33 @@ def test_fast_bilateral_filter_with_the_range_table_is_within_one_lsb(oracle, si
             assert d.max() <= 1, f"{what} {ww}x{ww} sigma_b {sb} at {w}x{h}: off by {d.max()} at {np.argwhere(d > 1)[:4].tolist()}"
 
 
+@pytest.mark.parametrize("size", [(203, 77), (64, 4), (5, 3), (3, 1), (130, 131), (261, 35)])
+def test_bilateral_filter_of_an_image_that_is_its_own_grey_image_is_bit_exact(oracle, size):
+    """ofx_bilateral_3ch with one device pointer for src and gray and a square window (main.cu:240) takes bilateral_exact_own_kernel
+    (one int per pixel in the tile, a 2 x 2 block per lane, the reference's double operations in the reference's order): the
+    oracle's bytes for every odd window up to 13, sizes off the 128 x 32 tile and off four pixels, narrow and wide range Gaussians
+    (denormal table entries included: sigma_b 1.5), images whose channels are equal, differ everywhere, or differ in one half."""
+    import torch
+
+    from cuda_optical_flow_2_amd import lib
+
+    L = lib.load()
+    w, h = size
+    rng = np.random.default_rng(w * 79 + h)
+    noise = oracle.grayscale_avg(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    smooth = synth.to_3ch(synth.smooth_pair(max(w, 8), max(h, 8), 0, 0, seed=9)[1])[:h, :w].copy()
+    colour = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    half = smooth.copy()
+    half[:, w // 2:, 1] ^= 0x10
+    st = torch.cuda.current_stream().cuda_stream
+    for (ww, ss, sb) in ((3, 0.8, 10.0), (5, 1.5, 20.0), (7, 1.0, 5.0), (9, 2.0, 10.0), (11, 2.5, 3.0), (13, 3.0, 40.0), (9, 2.0, 400.0), (9, 2.0, 1.5)):
+        for img, what in ((noise, "noise"), (smooth, "smooth"), (colour, "colour"), (half, "half colour")):
+            d_img = torch.from_numpy(img).cuda()
+            d_out = torch.full_like(d_img, 0x5a)
+            lib.check(L.ofx_bilateral_3ch(d_img.data_ptr(), d_img.data_ptr(), d_out.data_ptr(), w, h, ww, ww, ss, sb, st), "exact")
+            assert_same(d_out.cpu().numpy(), oracle.bilateral_3ch(img, img, ww, ww, ss, sb), f"{what} {ww}x{ww} sigma_b {sb} at {w}x{h}")
+
+
 _SPLIT_SNIPPET = """
 import sys
 sys.path.insert(0, {root!r})
