@@ -20,7 +20,7 @@ OBJ = os.path.join(PKG, "csrc", "_obj" + os.environ.get("OFX_BUILD_TAG", ""))
 ARCH = "gfx950"
 
 SOURCES = ["lk_inst_stream_f8.hip", "lk_inst_stream_fast8.hip", "lk_inst_stream_fw.hip", "lk_inst_stream_fastw.hip", "lk_inst_stream_fwr.hip", "lk_inst_stream_fastwr.hip", "lk_inst_iter_f4.hip", "lk_inst_iter_fast4.hip", "lk_inst_stream_f.hip", "lk_inst_stream_fast.hip", "lk_inst_stream_c.hip", "lk_inst_levels_f.hip", "lk_inst_levels_fast.hip",
-           "lk_inst_levels_c.hip", "lk_inst_iter_f2.hip", "lk_inst_iter_fast2.hip", "lk_inst_iter_f3.hip", "lk_inst_iter_fast3.hip", "lk_inst_iter_f1.hip", "lk_inst_iter_fast1.hip", "lk_level.hip", "corner.hip", "pyramid.hip", "primitives.hip", "srm_march.hip", "ofx_core.cpp", "session.cpp",
+           "lk_inst_levels_c.hip", "lk_inst_iter_f2.hip", "lk_inst_iter_fast2.hip", "lk_inst_iter_f3.hip", "lk_inst_iter_fast3.hip", "lk_inst_iter_f1.hip", "lk_inst_iter_fast1.hip", "lk_level.hip", "corner.hip", "pyr_corner.hip", "pyramid.hip", "primitives.hip", "srm_march.hip", "ofx_core.cpp", "session.cpp",
            "compat_gpu.cpp", "compat_cpu.cpp", "compat_stage.cpp"]
 # -ffp-contract=off: parity with the reference's x86-64 CPU build, which never fuses a*b+c (parity)
 # -fno-slp-vectorize: hipcc otherwise packs scalar fp32 adds/fmas into v_pk_* pairs, which costs register moves and

@@ -52,6 +52,7 @@ struct PatchBuild {
     int pw[OFX_MAX_LEVELS], ph[OFX_MAX_LEVELS], pitch[OFX_MAX_LEVELS]; // [0]: the patch of the frame itself (pitch: per slot)
     int off[OFX_MAX_LEVELS];                 // byte offset of level k inside a frame's patch planes
     int frame_stride;                        // bytes between the planes of the slot's two frames
+    int first;                               // 0: build both frames' planes; 1: only the second's (pyr_corner.hip: the first's are at hand)
 };
 struct PatchBuildSlot {
     const uint8_t *src[2]; // the frames (level 0, whole rows from column 0)
@@ -67,7 +68,7 @@ __device__ __forceinline__ void patch_build_block(const PatchBuild &P, const Pat
         // four groups per thread and pass, all their loads before the first store: the block is alone on its SIMDs' issue
         // slots only in name (it shares them with LK waves), and a chain of one group at a time -- nine dependent loads, a
         // store -- took ~60-90 us for the two patches of a 4K pair
-        for (int i0 = tid; i0 < 2 * per_frame; i0 += 4 * 256) {
+        for (int i0 = P.first * per_frame + tid; i0 < 2 * per_frame; i0 += 4 * 256) {
             uint32_t v[4];
             uint8_t *dst[4];
 #pragma unroll
@@ -150,6 +151,7 @@ __device__ __forceinline__ void patch_build_reloc(const PatchBuild &P, const uin
 constexpr int kCornerPrevDim = 16, kCornerNextDim = 32;
 constexpr int kCornerCacheBytes = kCornerPrevDim * kCornerPrevDim + kCornerNextDim * kCornerNextDim; // per level
 constexpr int kCornerTileBytes = 2 * kCornerPrevDim * kCornerPrevDim;                                 // the resolved tiles
+constexpr int kCornerScratch = 128; // LDS in front of a corner block's cache: the chain's floats, then corner_block's hand-over words
 constexpr int kCornerMaxRadius = kCornerPrevDim - 3; // the cached prev corner must hold the window and its stencils
 
 struct CornerCache {

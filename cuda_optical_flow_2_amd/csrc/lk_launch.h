@@ -15,7 +15,7 @@ using namespace ofx_dev;
 
 namespace ofx_launch { // types that cross translation units
 constexpr int kPyrStages = 2 * OFX_STREAM_MAX_BATCH; // per frame of the tick: its pyramid and its top-left patch pyramid
-constexpr int kCornerScratch = 128;                  // LDS of a corner block: the chain's floats, then the cached corners
+using ofx_dev::kCornerScratch;                       // LDS of a corner block: the chain's floats, then the cached corners
 struct StreamArgs {
     LkTable lk;
     PyrMarchArgs pyr[kPyrStages];

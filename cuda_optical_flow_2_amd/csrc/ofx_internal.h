@@ -75,6 +75,9 @@ int ofx_shift_table(const ofx_shift_desc *levels, int n, ofx_dev::ShiftTable *ou
 // shard_rows (NULL: unchecked): 4 ints per level, CornerLevel::need0 .. valid1
 int ofx_corner_args(const ofx_lk_desc *levels, int n_levels, int window, int mode, float *d_uv, const int *cols, int *d_status,
                     const int *shard_rows, ofx_dev::CornerHead *out, ofx_dev::CornerLevel *lv_out);
+// the pair-at-a-time path's pyramid launch with the pair's corner chain aboard (pyr_corner.hip); C->build_patch must be set
+int ofx_pyramid_corner_1ch(const uint8_t *d_level0, int pitch0, int w, int h, uint8_t *const *d_levels, const int *pitches, int levels,
+                           const ofx_corner_stage *C, int first, int window, int mode, void *stream);
 // sharded sessions whose shift vectors come from another rank: raise status bit 8 + k when level k's vertical shift sends the
 // shard's reads (rows [need0, need1) before the shift) to image rows outside [valid0, valid1); shard_rows = 4 ints per level
 int ofx_shard_margin_check(const float *d_uv, int levels, const int *heights, const int *shard_rows, int *d_status, void *stream);

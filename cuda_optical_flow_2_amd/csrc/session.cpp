@@ -63,6 +63,13 @@ struct ofx_session {
     // (borrow_frames) and the chain reads a patch (stream_two_stage, local_corner).
     uint8_t *preloc[kMaxBatch][OFX_MAX_LEVELS]{};
     bool repair = false;
+    // pair-at-a-time sessions (neither local_corner nor stream_two_stage, whole frames): ofx_session_build_pyramid also walks the
+    // pair's corner chain in one more block of its launch (pyr_corner.hip) on patch planes that block builds: pscr[0][0 / 1] hold the
+    // patch pyramids of two image sets in turn (pset_img / pset_gen: which set's, and of which load), preloc[0] the repair's planes
+    bool plain_fuse = false;
+    bool corner_done = false; // the shift vectors of the pair (prev, next) are in uv_cur() already
+    int pset_img[2] = {-1, -1};
+    long pset_gen[2] = {0, 0}, img_gen[3] = {0, 0, 0};
     int debug_extent = 0; // test hook (OFX_DEBUG_CORNER_EXTENT): the chain may only read this many level-0 columns / rows of its patch planes
     int *corner_status = nullptr;
     int *pair_status = nullptr; // one word per shift-vector slot (pair p -> slot p mod 2B)
@@ -233,10 +240,20 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     size_t pscr_frame = 0;
     const int n_slots = p->stream_batch >= 2 ? p->stream_batch : 1;
     size_t patch_bytes[OFX_MAX_LEVELS] = {};
-    if (p->local_corner || p->stream_two_stage) {
+    // OFX_PLAIN_FUSED=1: the pair-at-a-time path's pyramid launch carries the pair's corner chain (two launches per pair instead of
+    // three).  Off by default: measured SLOWER -- the chain's block takes 42-57 us inside the busy launch against 13.5 (pyramid) +
+    // 12.1 us (a lone corner wave on an idle chip) apart; profiles/r04_ablation.txt batch 10.
+    const bool plain_fuse_wanted = !p->local_corner && !p->stream_two_stage && !p->sharded && p->levels >= 2 && p->levels - 1 <= 6 &&
+                                   [] { const char *e = getenv("OFX_PLAIN_FUSED"); return e && atoi(e) != 0; }();
+    bool plain_repair = false;
+    if (p->local_corner || p->stream_two_stage || plain_fuse_wanted) {
         const int step = 1 << (p->levels - 1);
         int side = p->patch_size > 0 ? p->patch_size : step * ((p->window >> 1) + 2 + 8);
         if (p->patch_size <= 0 && side < 256) side = 256;
+        if (plain_fuse_wanted && p->patch_size <= 0) { // (experiment: the side of the pair-at-a-time chain's patch)
+            const char *e = getenv("OFX_PLAIN_PATCH");
+            if (e && atoi(e) > 0) side = atoi(e);
+        }
         side = (int)align_up((size_t)side, (size_t)step);
         const int pw0 = side < p->width ? side : p->width, ph0 = side < p->height ? side : p->height;
         for (int k = 0; k < p->levels; ++k) {
@@ -247,7 +264,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         }
         const int need = (p->window >> 1) + 2;
         const int lc = p->levels - 1;
-        if (s->pw[lc] < (need < s->w[lc] ? need : s->w[lc]) || s->ph[lc] < (need < s->h[lc] ? need : s->h[lc])) {
+        if (!plain_fuse_wanted && (s->pw[lc] < (need < s->w[lc] ? need : s->w[lc]) || s->ph[lc] < (need < s->h[lc] ? need : s->h[lc]))) {
             ofx_set_error("ofx_session_create: patch_size %d leaves %dx%d at the coarsest level, the corner needs %d", side, s->pw[lc],
                           s->ph[lc], need);
             delete s;
@@ -258,20 +275,31 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
         // target (radius + 3 pixels of stencils + the plane's first column / row); a smaller patch (patch_size) keeps the
         // status bit.
         const int need_r = (p->window >> 1) + 5;
-        s->repair = p->borrow_frames && !p->frames_partial && p->levels >= 3 && (s->pw[lc] >= need_r || s->pw[lc] >= s->w[lc]) && (s->ph[lc] >= need_r || s->ph[lc] >= s->h[lc]);
+        const bool room = (s->pw[lc] >= need_r || s->pw[lc] >= s->w[lc]) && (s->ph[lc] >= need_r || s->ph[lc] >= s->h[lc]);
+        s->repair = !plain_fuse_wanted && p->borrow_frames && !p->frames_partial && p->levels >= 3 && room;
+        if (plain_fuse_wanted) {
+            // the chain of such a session must be exact for every input (the stand-alone corner kernel reads whole planes): fused
+            // only where a miss can be repaired, or cannot happen because the patch is the frame; even patch dimensions below the top
+            const bool whole = pw0 == p->width && ph0 == p->height;
+            const bool enough = s->pw[lc] >= (need < s->w[lc] ? need : s->w[lc]) && s->ph[lc] >= (need < s->h[lc] ? need : s->h[lc]);
+            bool even = true;
+            for (int k = 0; k + 1 < p->levels; ++k) even = even && (s->pw[k] & 1) == 0 && (s->ph[k] & 1) == 0;
+            plain_repair = p->levels >= 3 && room && !whole;
+            s->plain_fuse = enough && even && (whole || plain_repair);
+        }
     }
-    if (s->repair) {
+    if (s->repair || plain_repair) {
         // Test hook: pretend the top-left patch planes are only this many level-0 pixels wide and high (never less than the
         // corner itself), so that ordinary frames drive the chain into the relocated planes; the results must not change.
         const char *e = getenv("OFX_DEBUG_CORNER_EXTENT");
         s->debug_extent = e ? atoi(e) : 0;
     }
-    const int frames_per_slot = (p->stream_two_stage ? 2 : 0) + (s->repair ? 1 : 0);
-    if (p->local_corner || p->stream_two_stage) {
+    const int frames_per_slot = (p->stream_two_stage || s->plain_fuse ? 2 : 0) + (s->repair || (s->plain_fuse && plain_repair) ? 1 : 0);
+    if (p->local_corner || p->stream_two_stage || s->plain_fuse) {
         for (int k = 0; k < p->levels; ++k) {
             off_pscr.push_back(pscr_frame);
             if (k >= 1) pscr_frame += patch_bytes[k];
-            if (p->stream_two_stage) continue; // no patch pyramids per image set: the corner blocks build what they read
+            if (p->stream_two_stage || s->plain_fuse) continue; // no patch pyramids per image set: the corner blocks build what they read
             for (int t = 0; t < n_sets; ++t) {
                 off_patch[t].push_back(total);
                 total += patch_bytes[k];
@@ -318,11 +346,11 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     for (int i = 0; i < n_slots && frames_per_slot > 0; ++i)
         for (int k = 1; k < p->levels; ++k) {
             uint8_t *slot = base + off_pscr[k] + (size_t)(frames_per_slot * i) * pscr_frame;
-            if (p->stream_two_stage) {
+            if (p->stream_two_stage || s->plain_fuse) {
                 s->pscr[i][0][k] = slot;
                 s->pscr[i][1][k] = slot + pscr_frame;
             }
-            if (s->repair) s->preloc[i][k] = slot + (size_t)(frames_per_slot - 1) * pscr_frame;
+            if (s->repair || (s->plain_fuse && plain_repair)) s->preloc[i][k] = slot + (size_t)(frames_per_slot - 1) * pscr_frame;
         }
     s->corner_status = reinterpret_cast<int *>(base + off_status);
     s->pair_status = s->corner_status + 1;
@@ -360,6 +388,13 @@ extern "C" int ofx_session_destroy(ofx_session *s)
     return OFX_OK;
 }
 
+// the image set of the next frame has new contents: patch planes built from its earlier contents and vectors formed with it are stale
+static void new_next(ofx_session *s)
+{
+    ++s->img_gen[(s->cur + 1) % 3];
+    s->corner_done = false;
+}
+
 // copy rows [buf0,buf1) of a tightly packed w-bytes-per-row frame into the level-0 `next` plane
 static int load_level0(ofx_session *s, const uint8_t *src, bool src_is_host, int src_pitch, hipStream_t st)
 {
@@ -371,6 +406,7 @@ static int load_level0(ofx_session *s, const uint8_t *src, bool src_is_host, int
     OFX_HIP(hipMemcpy2DAsync(s->plane[1][0], (size_t)s->pitch[0], src + (size_t)s->buf0[0] * (size_t)src_pitch, (size_t)src_pitch,
                              (size_t)s->w[0], (size_t)rows, src_is_host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
     s->have_next = true;
+    new_next(s);
     return OFX_OK;
 }
 
@@ -392,7 +428,8 @@ extern "C" int ofx_session_set_frame_device(ofx_session *s, const uint8_t *d_gra
                     "got %d) and a 4-byte aligned address", s->pitch[0], pitch);
         s->pframe[(s->cur + 1) % 3] = d_gray1;
         repoint(s);
-            s->have_next = true;
+        s->have_next = true;
+        new_next(s);
         return OFX_OK;
     }
     return load_level0(s, d_gray1, false, pitch, ofx_stream(stream));
@@ -411,6 +448,7 @@ extern "C" int ofx_session_set_frame_host_3ch(ofx_session *s, const uint8_t *h_i
     // the reference reads channel 0 only (OptFlowCPU.cpp:102, OptFlowGpu.cu:1079)
     OFX_TRY(ofx_extract_ch0(s->staging, s->plane[1][0], s->w[0], s->h[0], s->pitch[0], stream));
     s->have_next = true;
+    new_next(s);
     return OFX_OK;
 }
 
@@ -433,6 +471,47 @@ static int build_pyramid(ofx_session *s, void *stream)
         for (int k = 1; k < s->p.levels; ++k) {
             lv[k] = s->plane[1][k];
             pitches[k] = s->pitch[k];
+        }
+        if (s->plain_fuse && s->have_prev && (s->pitch0_next() & 3) == 0 && (((uintptr_t)s->plane[0][0] | (uintptr_t)s->plane[1][0]) & 3) == 0) {
+            // the pair's corner chain rides in one more block of this launch (pyr_corner.hip); ofx_session_corner_flows then has
+            // nothing left to do.  The previous frame's patch planes: the ones built when it was the next frame, if they still are.
+            const int L = s->p.levels, ip = s->cur, in = (s->cur + 1) % 3;
+            int have = -1;
+            for (int t = 0; t < 2; ++t)
+                if (s->pset_img[t] == ip && s->pset_gen[t] == s->img_gen[ip]) have = t;
+            const int tp = have >= 0 ? have : 0, tn = 1 - tp;
+            ofx_corner_stage C{};
+            C.levels = L;
+            C.d_uv = s->uv_cur();
+            C.build_patch = 1;
+            C.patch_w = s->pw[0];
+            C.patch_h = s->ph[0];
+            C.d_patch_src[0] = s->plane[0][0], C.d_patch_src[1] = s->plane[1][0];
+            C.patch_src_pitch[0] = s->pitch[0], C.patch_src_pitch[1] = s->pitch0_next();
+            auto extent = [&](int k, int full) { // (OFX_DEBUG_CORNER_EXTENT: as the stream pipeline's chain_extent)
+                if (s->debug_extent <= 0 || k == 0 || s->preloc[0][1] == nullptr) return full;
+                const int need = (s->p.window >> 1) + 2, lim = s->debug_extent >> k;
+                const int e = lim > need ? lim : need;
+                return e < full ? e : full;
+            };
+            for (int k = 0; k < L; ++k) {
+                C.patch_pitch[k] = s->ppitch[k];
+                C.d_patch[0][k] = s->pscr[0][tp][k];
+                C.d_patch[1][k] = s->pscr[0][tn][k];
+                C.d_patch_reloc[k] = s->preloc[0][k];
+                const uint8_t *pp = k ? s->pscr[0][tp][k] : s->plane[0][0], *pn = k ? s->pscr[0][tn][k] : s->plane[1][0];
+                ofx_geom pg{s->w[k], s->h[k], k ? s->ppitch[k] : s->pitch[0], 0, k ? extent(k, s->ph[k]) : s->h[0], 0, k ? extent(k, s->ph[k]) : s->h[0]};
+                C.level[k] = ofx_lk_desc{pp, pn, pg, nullptr, 0, nullptr, 0, s->p.min_det};
+                C.cols[k] = k ? extent(k, s->pw[k]) : 0;
+            }
+            OFX_TRY(timed_launch(s, OFX_TIME_PYRAMID, stream, [&] {
+                return ofx_pyramid_corner_1ch(s->plane[1][0], s->pitch0_next(), s->w[0], s->h[0], lv, pitches, L, &C, have >= 0 ? 1 : 0, s->p.window, s->p.mode,
+                                              stream);
+            }));
+            s->pset_img[tp] = ip, s->pset_gen[tp] = s->img_gen[ip];
+            s->pset_img[tn] = in, s->pset_gen[tn] = s->img_gen[in];
+            s->corner_done = true;
+            return OFX_OK;
         }
         return timed_launch(s, OFX_TIME_PYRAMID, stream,
                             [&] { return ofx_pyramid_1ch(s->plane[1][0], s->pitch0_next(), s->w[0], s->h[0], lv, pitches, s->p.levels, stream); });
@@ -548,6 +627,7 @@ extern "C" int ofx_session_corner_flows(ofx_session *s, void *stream)
         ofx_set_error("ofx_session_corner_flows: need a previous and a next frame");
         return OFX_E_STATE;
     }
+    if (s->corner_done) return OFX_OK; // (ofx_session_build_pyramid's launch has formed them: pyr_corner.hip)
     ofx_lk_desc d[OFX_MAX_LEVELS];
     for (int k = 0; k < s->p.levels; ++k)
         d[k] = ofx_lk_desc{s->plane[0][k], s->plane[1][k], level_geom(s, k, s->own0[k], s->own1[k]), nullptr, s->own0[k], nullptr, 0, s->p.min_det};
@@ -670,6 +750,7 @@ extern "C" int ofx_session_swap(ofx_session *s)
     s->have_prev = s->have_next;
     s->have_next = false;
     s->staged = false;
+    s->corner_done = false;
     return OFX_OK;
 }
 
@@ -1103,6 +1184,8 @@ extern "C" int ofx_session_stream_begin(ofx_session *s)
     s->reported = 0;
     s->corner_newest = 0;
     s->have_prev = s->have_next = s->staged = false;
+    s->corner_done = false;
+    s->pset_img[0] = s->pset_img[1] = -1;
     for (int k = 0; k < s->p.levels; ++k) s->flow[k] = s->flowset[0][k];
     return OFX_OK;
 }

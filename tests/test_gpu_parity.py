@@ -1586,3 +1586,62 @@ def test_march_with_eight_columns_per_lane_is_bit_identical(eng):
     env = dict(os.environ, OFX_LK_COLS="4", OFX_LK_PLAIN_COLS="8")   # the narrow tick against the wide pair-at-a-time launch
     r = subprocess.run([_sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "wide ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+_PLAIN_FUSED_SNIPPET = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from cuda_optical_flow_2_amd import engine as eng, synth
+
+out = {{}}
+for (w, h, L, win, mode) in ((1280, 720, 5, 9, "lk_float"), (640, 480, 4, 15, "compat_cpu"), (400, 304, 3, 7, "lk_float"), (64, 48, 3, 5, "lk_float")):
+    frames = [synth.smooth_pair(w, h, 1.3 * i, -0.7 * i, seed=37)[1] for i in range(4)]
+    frames[2] = synth.random_pair(w, h, 9)[0]   # (a corner whose vectors are large or not finite: the chain leaves its patch)
+    s = eng.Session(w, h, L, win, mode)
+    s.set_frame_host(frames[0]); s.build_pyramid(); s.swap()
+    for i in range(1, 4):
+        s.timing(8)
+        s.set_frame_host(frames[i]); s.build_pyramid(); s.run_flow()
+        torch.cuda.synchronize()
+        out[f"{{w}}_{{mode}}_{{i}}_launches"] = np.array([s.timing_read_kind("pyramid")[2], s.timing_read_kind("corner")[2], s.timing_read_kind("lk")[2]])
+        s.timing(0)
+        for k in range(L):
+            out[f"{{w}}_{{mode}}_{{i}}_{{k}}"] = s.flow_host(k)
+        for k in range(L - 1):
+            out[f"{{w}}_{{mode}}_{{i}}_uv{{k}}"] = s.uv(k).cpu().numpy().copy()
+        s.swap()
+    s.close()
+np.savez(sys.argv[1], **out)
+print("plain ok")
+"""
+
+
+def test_pyramid_launch_that_carries_the_corner_chain_gives_the_same_flows(tmp_path):
+    """csrc/pyr_corner.hip (round 4, OFX_PLAIN_FUSED=1; measured slower than the three launches, so not the default): the pair-at-a-time
+    path's pyramid launch walks the pair's corner chain in one more block, on a patch pyramid that block builds (the previous
+    frame's patch planes are kept from the pair before), and repairs a shift that leaves the patch from the whole level 0.  Child
+    processes run three consecutive pairs of four configurations -- the default three launches; the fused two; the fused two with
+    the chain's planes narrowed to 48 level-0 pixels so that ordinary frames need the repair too -- and every flow and every shift
+    vector must be bit-identical; the fused children must show one pyramid launch, no corner launch, one LK launch per pair."""
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, extra in (("default", {}), ("fused", {"OFX_PLAIN_FUSED": "1"}), ("fused_narrow", {"OFX_PLAIN_FUSED": "1", "OFX_DEBUG_CORNER_EXTENT": "48"})):
+        path = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([_sys.executable, "-c", _PLAIN_FUSED_SNIPPET.format(root=root), path], env=dict(os.environ, **extra), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "plain ok" in r.stdout, (name, r.stdout[-500:], r.stderr[-2000:])
+        got[name] = dict(np.load(path))
+    for name in ("fused", "fused_narrow"):
+        fused_pairs = 0
+        for k, v in got["default"].items():
+            if k.endswith("_launches"):
+                assert v.tolist() == [1, 1, 1], (k, v)
+                fused_pairs += int(got[name][k].tolist() == [1, 0, 1])
+                continue
+            a, b = got[name][k], v
+            assert a.shape == b.shape and bool(((a == b) | (np.isnan(a) & np.isnan(b))).all()), (name, k)
+        assert fused_pairs >= 9, (name, fused_pairs)   # (the 64 x 48 session's patch is the frame: fused too; at least the three larger ones)
