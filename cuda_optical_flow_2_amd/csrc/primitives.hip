@@ -39,6 +39,34 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *src3, uint8_t 
     d[0] = d[1] = d[2] = g;
 }
 
+// The same, sixteen pixels = 48 bytes = three 16-byte pieces per thread (4-byte aligned images): the byte-per-instruction form above
+// spends 18 us on a 4K frame whose 50 MB take 10 us at the part's copy rate.  A piece's sixteen bytes hold the channels of 5 1/3
+// pixels; the sums are formed on the 12 dwords in registers and every output byte is its pixel's average.
+__global__ __launch_bounds__(256) void gray_x16_kernel(const uint32_t *src, uint32_t *dst, size_t n16)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n16) return;
+    const uint4 *s = reinterpret_cast<const uint4 *>(src + 12 * t);
+    const uint4 a = s[0], b = s[1], c = s[2];
+    const uint32_t in[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+    uint32_t out[12];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { // four pixels in three dwords
+        const uint32_t d0 = in[3 * q], d1 = in[3 * q + 1], d2 = in[3 * q + 2];
+        const uint32_t g0 = ((d0 & 0xffu) + ((d0 >> 8) & 0xffu) + ((d0 >> 16) & 0xffu)) / 3u;
+        const uint32_t g1 = ((d0 >> 24) + (d1 & 0xffu) + ((d1 >> 8) & 0xffu)) / 3u;
+        const uint32_t g2 = (((d1 >> 16) & 0xffu) + (d1 >> 24) + (d2 & 0xffu)) / 3u;
+        const uint32_t g3 = (((d2 >> 8) & 0xffu) + ((d2 >> 16) & 0xffu) + (d2 >> 24)) / 3u;
+        out[3 * q] = g0 * 0x010101u | (g1 << 24);
+        out[3 * q + 1] = g1 * 0x0101u | (g2 * 0x01010000u);
+        out[3 * q + 2] = g2 | (g3 * 0x01010100u);
+    }
+    uint4 *d = reinterpret_cast<uint4 *>(dst + 12 * t);
+    d[0] = uint4{out[0], out[1], out[2], out[3]};
+    d[1] = uint4{out[4], out[5], out[6], out[7]};
+    d[2] = uint4{out[8], out[9], out[10], out[11]};
+}
+
 // int accumulator, float add, truncation after every tap (OptFlowCPU.cpp:62,102 == OptFlowGpu.cu:137-139,414)
 __device__ __forceinline__ int acc_trunc(int acc, int px, float m) { return (int)((float)acc + (float)px * m); }
 
@@ -1106,8 +1134,19 @@ extern "C" int ofx_grayscale_avg_3ch(const uint8_t *d_src3, uint8_t *d_dst3, int
 {
     OFX_REQUIRE(d_src3 && d_dst3 && w > 0 && h > 0, "ofx_grayscale_avg_3ch: bad arguments");
     const size_t n = (size_t)w * (size_t)h;
-    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_src3, d_dst3, n);
-    OFX_HIP(hipGetLastError());
+    size_t done = 0;
+    if ((((uintptr_t)d_src3 | (uintptr_t)d_dst3) & 15) == 0 && n >= 16) { // sixteen pixels per thread; the last n % 16 pixels below
+        const size_t n16 = n / 16;
+        hipLaunchKernelGGL(gray_x16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, ofx_stream(stream), reinterpret_cast<const uint32_t *>(d_src3),
+                           reinterpret_cast<uint32_t *>(d_dst3), n16);
+        OFX_HIP(hipGetLastError());
+        done = 16 * n16;
+    }
+    if (done < n) {
+        hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, ofx_stream(stream), d_src3 + 3 * done, d_dst3 + 3 * done,
+                           n - done);
+        OFX_HIP(hipGetLastError());
+    }
     return OFX_OK;
 }
 

@@ -285,6 +285,30 @@ def test_bilateral_filter_of_an_image_that_is_its_own_grey_image_is_bit_exact(or
             assert_same(d_out.cpu().numpy(), oracle.bilateral_3ch(img, img, ww, ww, ss, sb), f"{what} {ww}x{ww} sigma_b {sb} at {w}x{h}")
 
 
+def test_grayscale_sixteen_pixels_per_thread_equals_the_oracle(oracle):
+    """ofx_grayscale_avg_3ch takes three 16-byte pieces = sixteen pixels per thread where both images are 16-byte aligned, the
+    byte-wise kernel for the last n % 16 pixels and for unaligned images: sizes around the multiples of 16, an image that starts
+    3 bytes into its allocation, every byte against the oracle (OptFlowCPU.cpp:27-28)."""
+    import torch
+
+    from cuda_optical_flow_2_amd import lib
+
+    L = lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    rng = np.random.default_rng(21)
+    for (w, h) in ((203, 77), (64, 4), (5, 3), (16, 1), (17, 1), (1, 1), (1920, 3), (255, 255)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = oracle.grayscale_avg(img)
+        for shift in (0, 3):
+            buf = torch.zeros(img.size + 64, dtype=torch.uint8, device="cuda")
+            out = torch.full((img.size + 64,), 0x5a, dtype=torch.uint8, device="cuda")
+            buf[shift:shift + img.size] = torch.from_numpy(img.reshape(-1)).cuda()
+            lib.check(L.ofx_grayscale_avg_3ch(buf.data_ptr() + shift, out.data_ptr() + shift, w, h, st), "grayscale")
+            got = out.cpu().numpy()
+            assert_same(got[shift:shift + img.size].reshape(h, w, 3), want, f"{w}x{h} at byte offset {shift}")
+            assert (got[:shift] == 0x5a).all() and (got[shift + img.size:] == 0x5a).all(), f"{w}x{h}: wrote outside the image"
+
+
 _SPLIT_SNIPPET = """
 import sys
 sys.path.insert(0, {root!r})
