@@ -98,7 +98,9 @@ int ofx_pyramid_corner_1ch(const uint8_t *d_level0, int pitch0, int w, int h, ui
     a.slot = PatchBuildSlot{{C->d_patch_src[0], C->d_patch_src[1]}, {C->patch_src_pitch[0], C->patch_src_pitch[1]}, C->d_patch[0][1]};
     const size_t corner_lds = (size_t)kCornerScratch + kCornerTileBytes + (size_t)levels * kCornerCacheBytes;
     const size_t lds = lds_bytes > corner_lds ? lds_bytes : corner_lds;
-    const dim3 grid((unsigned)(bx * by + 1));
+    // (experiment, wrong results: OFX_X_CHAIN_ONLY=1 launches the chain's block alone -- what it costs on an idle chip)
+    static const bool chain_only = [] { const char *e = getenv("OFX_X_CHAIN_ONLY"); return e && atoi(e) != 0; }();
+    const dim3 grid((unsigned)(chain_only ? 1 : bx * by + 1));
     hipStream_t st = ofx_stream(stream);
     if (mode == OFX_MODE_LK_FLOAT) hipLaunchKernelGGL((pyramid_corner_kernel<OFX_MODE_LK_FLOAT, false>), grid, dim3(kPyrThreads), lds, st, a);
     else if (mode == OFX_MODE_LK_FLOAT_FAST) hipLaunchKernelGGL((pyramid_corner_kernel<OFX_MODE_LK_FLOAT, true>), grid, dim3(kPyrThreads), lds, st, a);

@@ -241,8 +241,8 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     const int n_slots = p->stream_batch >= 2 ? p->stream_batch : 1;
     size_t patch_bytes[OFX_MAX_LEVELS] = {};
     // OFX_PLAIN_FUSED=1: the pair-at-a-time path's pyramid launch carries the pair's corner chain (two launches per pair instead of
-    // three).  Off by default: measured SLOWER -- the chain's block takes 42-57 us inside the busy launch against 13.5 (pyramid) +
-    // 12.1 us (a lone corner wave on an idle chip) apart; profiles/r04_ablation.txt batch 10.
+    // three).  Off by default: measured SLOWER -- the chain's block takes 42-57 us (28-44 of them its patch build) against 13.5
+    // (pyramid) + 12.1 us (the lone corner wave reading the finished pyramid) apart; profiles/r04_ablation.txt batch 10.
     const bool plain_fuse_wanted = !p->local_corner && !p->stream_two_stage && !p->sharded && p->levels >= 2 && p->levels - 1 <= 6 &&
                                    [] { const char *e = getenv("OFX_PLAIN_FUSED"); return e && atoi(e) != 0; }();
     bool plain_repair = false;
