@@ -60,32 +60,40 @@ struct PatchBuildSlot {
     uint8_t *base;         // this slot's planes: frame f's level k at base + f * frame_stride + off[k]
 };
 
+#ifndef OFX_PATCH_ITEMS
+#define OFX_PATCH_ITEMS 2 // work items (a group of four pixels on two rows: fifteen loads) a thread has in flight per pass (4: the stream kernels spill)
+#endif
 __device__ __forceinline__ void patch_build_block(const PatchBuild &P, const PatchBuildSlot &S, int tid)
 {
     for (int k = 1; k <= P.n; ++k) {
+        // an item = four adjacent pixels of two rows from ONE set of fifteen loads, all issued before the first use (down4x2; until
+        // round 4 this was one row at a time through the generic down4, whose guarded loads and per-tap arithmetic made the two
+        // patches of a 4K pair cost ~45 us of a block that then walks a 10 us chain -- profiles/r04_ablation.txt batch 10)
         const int groups = (P.pw[k] + 3) / 4; // (the pitch covers the last group: it is the width rounded up to 64)
-        const int per_frame = groups * P.ph[k];
-        // four groups per thread and pass, all their loads before the first store: the block is alone on its SIMDs' issue
-        // slots only in name (it shares them with LK waves), and a chain of one group at a time -- nine dependent loads, a
-        // store -- took ~60-90 us for the two patches of a 4K pair
-        for (int i0 = P.first * per_frame + tid; i0 < 2 * per_frame; i0 += 4 * 256) {
-            uint32_t v[4];
-            uint8_t *dst[4];
+        const int per_frame = groups * ((P.ph[k] + 1) / 2);
+        for (int i0 = P.first * per_frame + tid; i0 < 2 * per_frame; i0 += OFX_PATCH_ITEMS * 256) {
+            uint32_t v[OFX_PATCH_ITEMS][2];
+            uint8_t *dst[OFX_PATCH_ITEMS];
+            bool two[OFX_PATCH_ITEMS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < OFX_PATCH_ITEMS; ++u) {
                 const int i = i0 + 256 * u;
                 const bool on = i < 2 * per_frame;
                 const int ic = on ? i : i0;
                 const int f = ic >= per_frame ? 1 : 0, j = ic - f * per_frame;
-                const int y = j / groups, x0 = 4 * (j - y * groups);
+                const int yp = j / groups, x0 = 4 * (j - yp * groups), y = 2 * yp;
                 const uint8_t *src = k == 1 ? S.src[f] : S.base + (size_t)f * (size_t)P.frame_stride + P.off[k - 1];
                 const int sp = k == 1 ? S.src_pitch[f] : P.pitch[k - 1];
-                v[u] = down4(src, sp, 0, 0, P.ph[k - 1], P.pw[k - 1], P.pw[k], x0, y);
+                down4x2<false>(src, sp, P.ph[k - 1], P.pw[k - 1], P.pw[k], P.ph[k], x0, y, v[u][0], v[u][1]);
                 dst[u] = on ? S.base + (size_t)f * (size_t)P.frame_stride + P.off[k] + (size_t)y * (size_t)P.pitch[k] + x0 : nullptr;
+                two[u] = y + 1 < P.ph[k];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (dst[u]) *reinterpret_cast<uint32_t *>(dst[u]) = v[u];
+            for (int u = 0; u < OFX_PATCH_ITEMS; ++u)
+                if (dst[u]) {
+                    *reinterpret_cast<uint32_t *>(dst[u]) = v[u][0];
+                    if (two[u]) *reinterpret_cast<uint32_t *>(dst[u] + P.pitch[k]) = v[u][1];
+                }
         }
         __syncthreads();
     }
