@@ -1,5 +1,6 @@
 # Round evidence for profiles/: rocprofv3 kernel stats of the bench command (the headline = config as written, iters = 1, plain path, compat_cpu, ...) and
-# HBM traffic per launch from separate --pmc passes (FETCH_SIZE / WRITE_SIZE; never combined with tracing).
+# HBM traffic per launch from separate --pmc passes (FETCH_SIZE / WRITE_SIZE; never combined with tracing) -- taken FIRST, so that the bench
+# lines of the profiled runs carry a traffic figure measured on the same sources.
 #   gpurun -- 'bash tools/profile_round.sh r04'      then copy gpurun_out/prof_<tag>/summary/* into profiles/ and stamp the commit:
 #   python tools/stamp_traffic.py   (the GPU box has no .git)
 set -e
@@ -9,29 +10,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O/summary
 cd $R
-stats() { # name, bench args...
-  n=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
-  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench4k_${n}_kernel_stats.csv
-  echo "== $n"; head -4 "$f"
-}
-stats headline
-stats iters1 --iters 1
-stats iters1_warm --iters 1 --ring 20
-stats plain --iters 1 --path plain
-stats iters5_plain --path plain --steps 200
-stats compat_cpu --iters 1 --mode compat_cpu
-stats random --iters 1 --frames random
-# the other BASELINE configurations as written: file names say which
-stats8() { n=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
-  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench_${n}_kernel_stats.csv
-  echo "== $n"; head -4 "$f"
-}
-stats8 8k_iters10 --workload 8k --steps 12 --warmup 4
-stats8 8k_iters1 --workload 8k --iters 1 --steps 200
-stats8 1080p_iters5 --workload 1080p --steps 50 --warmup 8
-stats8 1080p_iters1 --workload 1080p --iters 1 --steps 500
 pmc() { # name, kernel substring, skip, pmc_run args...
   n=$1; k=$2; skip=$3; shift 3
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -67,6 +45,31 @@ out = {"4k": {n: r.get("bytes") for n, r in zip(names, rows)}, "pairs_per_launch
 print(json.dumps(out, indent=1))
 PY
 cat $O/summary/traffic_latest.json
+# the bench lines below carry this figure: bench.py reads profiles/traffic_latest.json and checks its kernel_source_sha16 against the sources
+cp $O/summary/traffic_latest.json $R/profiles/traffic_latest.json
+stats() { # name, bench args...
+  n=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
+  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench4k_${n}_kernel_stats.csv
+  echo "== $n"; head -4 "$f"
+}
+stats headline
+stats iters1 --iters 1
+stats iters1_warm --iters 1 --ring 20
+stats plain --iters 1 --path plain
+stats iters5_plain --path plain --steps 200
+stats compat_cpu --iters 1 --mode compat_cpu
+stats random --iters 1 --frames random
+# the other BASELINE configurations as written: file names say which
+stats8() { n=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
+  f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench_${n}_kernel_stats.csv
+  echo "== $n"; head -4 "$f"
+}
+stats8 8k_iters10 --workload 8k --steps 12 --warmup 4
+stats8 8k_iters1 --workload 8k --iters 1 --steps 200
+stats8 1080p_iters5 --workload 1080p --steps 50 --warmup 8
+stats8 1080p_iters1 --workload 1080p --iters 1 --steps 500
 # keep the merge small: drop the big traces
 find $O -name "*kernel_trace.csv" -delete
 find $O -name "*counter_collection.csv" -size +2M -delete
