@@ -375,6 +375,15 @@ def cold_ring_size(batch, two_stage, frame_bytes):
     return n
 
 
+def frames_hint(n_buffers, frame_bytes):
+    """ofx_params.deep_fetch for a ring of never-rewritten buffers: +1 (cold: each comes back from HBM) when the ring is longer than
+    the Infinity Cache, -1 (warm) when it fits.  OFX_BENCH_DEEP_FETCH=-1|0|1 overrides (0 = the library's own choice by level size)."""
+    e = os.environ.get("OFX_BENCH_DEEP_FETCH")
+    if e is not None:
+        return int(e)
+    return 1 if n_buffers * frame_bytes > INFINITY_CACHE_BYTES else -1
+
+
 def make_ring(src, n):
     """n DISTINCT device buffers whose contents repeat every len(src) buffers"""
     return [src[i % len(src)] if i < len(src) else src[i % len(src)].clone() for i in range(n)]
@@ -508,7 +517,7 @@ class Run:
             self.sess = sess = engine.Session(w, h, levels, window, args.mode, device=self.local_rank, iters=args.iters,
                                               stream_batch=args.batch if args.path == "stream" else 1,
                                               borrow_frames=args.borrow and (args.path == "stream" or (args.path == "plain" and w % 64 == 0)),
-                                              two_stage=args.two_stage)
+                                              two_stage=args.two_stage, deep_fetch=frames_hint(self.ring_n, w * h))
             sess.push_frame_host(self.frames[0])
             if args.path == "stream":
                 # one launch per tick: pyramid(newest frames) | corner(the pairs before) | fused LK(the pairs before those, global shift
@@ -681,7 +690,8 @@ class Run:
         two_stage = (self.args.two_stage and borrow) if two_stage is None else two_stage   # like the main run wherever the frames are borrowed
         two_stage = bool(two_stage and iters <= 1)   # (with iterations the tick is a quarter of a pair's time; two stages measured no gain)
         assert len(ring) >= (2 if two_stage else 3) * batch + 1 or not borrow, "the ring is too short for borrowed frames"
-        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage, iters=iters)
+        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=borrow, two_stage=two_stage, iters=iters,
+                            deep_fetch=frames_hint(len(ring), w2 * h2))
         s2.stream_begin()
         fd = StreamFeed(s2.stream_submit_frames, ring, batch)
         t_end = time.perf_counter() + 0.15
@@ -890,7 +900,8 @@ class Run:
         w2, h2, l2, win2 = wl
         src = [torch.from_numpy(f).cuda() for f in self.host_frames(w2, h2)]
         ring = make_ring(src, ring_size(batch, two_stage))   # the SHORT ring on purpose: freshness comes from the rewrite, not from its length
-        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=True, two_stage=two_stage)
+        s2 = engine.Session(w2, h2, l2, win2, mode, device=self.local_rank, stream_batch=batch, borrow_frames=True, two_stage=two_stage,
+                            deep_fetch=-1 if w2 * h2 < 16_000_000 else 0)   # (just written: warm)
         s2.stream_begin()
         n = len(ring)
         groups = [engine.FrameGroup([ring[(j * batch + k) % n] for k in range(batch)]) for j in range(math.lcm(n, batch) // batch)]
@@ -1187,7 +1198,8 @@ class Run:
         ring_what = (f"a ring of {self.ring_n} distinct device buffers = {ring_mb:.0f} MB " +
                      ("(larger than the 256 MiB Infinity Cache: a buffer that comes round again is read from HBM)" if ring_mb * 1e6 > INFINITY_CACHE_BYTES
                       else "(SMALLER than the 256 MiB Infinity Cache: re-used buffers are served from it)") +
-                     "; contents never rewritten -- extra.fresh_frames rewrites every buffer before its tick")
+                     "; contents never rewritten -- extra.fresh_frames rewrites every buffer before its tick" +
+                     (f"; the session is told so (ofx_params.deep_fetch = {frames_hint(self.ring_n, w * h):+d}: a speed hint, same bits)" if driver is None and stream_like else ""))
         if driver is not None and args.shard_halo == "stream_exchange":
             o0, o1 = driver.plan.own[0]
             frames_cfg = (f"every rank is handed ONLY ITS OWN ROWS of a frame ({o1 - o0} of {h} on rank 0; a stacked tensor per tick out of {ring_what}); per tick the "

@@ -105,11 +105,13 @@ namespace ofx_launch { // shared by the translation units that instantiate the k
 extern unsigned long long *g_stream_trace; // tools/stream_timeline.py
 extern int g_stream_trace_blocks;
 extern int g_trace_header[2 * OFX_STREAM_MAX_BATCH + 1];
+extern thread_local int g_stream_deep_fetch; // ofx_stream_stages.deep_fetch of the launch being dispatched (set by ofx_stream_launch)
 } // namespace ofx_launch
 namespace {
 using ofx_launch::g_stream_trace;
 using ofx_launch::g_stream_trace_blocks;
 using ofx_launch::g_trace_header;
+using ofx_launch::g_stream_deep_fetch;
 
 // lk_float fits 5 blocks per CU (<= 96 VGPRs) without scratch for every radius; compat_cpu needs ~120: 4 blocks (<= 128)
 #ifndef OFX_PYR_PRIO
@@ -401,7 +403,11 @@ int launch_stream_r(const LkLevelIn *lv, int n, StreamArgs &S, const int *stage_
         static const int forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
         long max_px = 0;
         for (int i = 0; i < n; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
-        if (forced > 0 || (forced < 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true, WOUT>(lv, n, S, stage_blocks, lds, st);
+        // (round 4, second session: WHERE the rows come from decides, not the level's size as such -- a ring of 4K or 1080p frames
+        // longer than the Infinity Cache gains 5 % / 3.5 % with the deep fetch, a warm one loses 2 %: the caller can say which,
+        // ofx_params.deep_fetch)
+        const int want = forced >= 0 ? (forced > 0 ? 1 : -1) : g_stream_deep_fetch;
+        if (want > 0 || (want == 0 && max_px >= 16l * 1000 * 1000)) return launch_stream_rd<R, MODE, FAST, true, WOUT>(lv, n, S, stage_blocks, lds, st);
     }
 #endif
     return launch_stream_rd<R, MODE, FAST, false, WOUT>(lv, n, S, stage_blocks, lds, st);

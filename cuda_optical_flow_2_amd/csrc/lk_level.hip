@@ -31,6 +31,7 @@ namespace ofx_launch {
 unsigned long long *g_stream_trace = nullptr; // tools/stream_timeline.py
 int g_stream_trace_blocks = 0;
 int g_trace_header[2 * OFX_STREAM_MAX_BATCH + 1] = {0};
+thread_local int g_stream_deep_fetch = 0;
 } // namespace ofx_launch
 
 namespace {
@@ -100,6 +101,7 @@ int lk_cols(const LkLevelIn *lv, int m, int radius)
     static const int forced = [] { const char *e = getenv("OFX_LK_COLS"); return e ? atoi(e) : 0; }();
     static const int dma_forced = [] { const char *e = getenv("OFX_LK_DMA"); return e ? atoi(e) : -1; }();
     if (radius < 1 || radius > 11 || m <= 0) return 4;
+    if (dma_forced < 0 && ofx_launch::g_stream_deep_fetch > 0) return 4;
     if (forced == 4 || forced == 8) return forced;
     long max_px = 0;
     for (int i = 0; i < m; ++i) max_px = (long)lv[i].a.w * lv[i].a.h > max_px ? (long)lv[i].a.w * lv[i].a.h : max_px;
@@ -271,6 +273,8 @@ extern "C" int ofx_stream_launch(const ofx_stream_stages *g, int window, int mod
     }
     if (any == 0 && m == 0 && g->n_corner == 0) return OFX_OK;
     hipStream_t st = ofx_stream(stream);
+    OFX_REQUIRE(g->deep_fetch >= -1 && g->deep_fetch <= 1, "ofx_stream_launch: deep_fetch must be -1, 0 or +1 (got %d)", g->deep_fetch);
+    ofx_launch::g_stream_deep_fetch = g->deep_fetch;
     if (m > 0 && lv[0].a.warp_out) { // the LK stage also writes the warped images of its pairs' second iteration (levels below 2 GB: checked above)
         bool rw = false; // a shard's row windows
         for (int i = 0; i < m; ++i) rw = rw || lv[i].a.row0 != 0 || lv[i].a.row_end != lv[i].a.h;

@@ -18,7 +18,7 @@ void ofx_set_error(const char *fmt, ...)
 
 extern "C" const char *ofx_last_error(void) { return g_err; }
 
-extern "C" int ofx_abi_version(void) { return 9; }
+extern "C" int ofx_abi_version(void) { return 10; }
 
 extern "C" int ofx_device_count(void)
 {

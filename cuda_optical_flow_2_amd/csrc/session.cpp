@@ -158,6 +158,7 @@ extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
     OFX_REQUIRE(!p->stream_two_stage || p->borrow_frames, "ofx_session_create: stream_two_stage needs borrow_frames (the corner stage reads "
                                                             "both frames of a pair in the tick in which the second one arrives)");
     OFX_REQUIRE(p->iters <= 1 || p->mode != OFX_MODE_COMPAT_CPU, "ofx_session_create: refinement iterations need mode lk_float");
+    OFX_REQUIRE(p->deep_fetch >= -1 && p->deep_fetch <= 1, "ofx_session_create: deep_fetch must be -1, 0 or +1 (got %d)", p->deep_fetch);
     OFX_REQUIRE(!p->frames_partial || (p->sharded && p->local_corner && !p->stream_two_stage),
                 "ofx_session_create: frames_partial describes the frames of a sharded local_corner session (not stream_two_stage)");
     OFX_REQUIRE(p->iters <= 1 || !p->sharded || p->local_corner,
@@ -1098,6 +1099,7 @@ static int stream_tick(ofx_session *s, const uint8_t *const *frames, const int *
         for (int k = 0; k < L; ++k) s->flow[k] = s->flowset[newest % B][k];
     }
     bool time_it = g.n_lk > 0;
+    g.deep_fetch = s->p.deep_fetch; // (ofx_params.deep_fetch: where the caller's frames come from)
 #ifdef OFX_EXPERIMENTS
     // stage ablation for timing experiments (tools/stream_timeline.py): the flows reported complete are then NOT computed, so
     // the knob only exists in builds made with -DOFX_EXPERIMENTS (OFX_BUILD_DEFS)

@@ -96,25 +96,38 @@ __global__ __launch_bounds__(256) void srm_u8_march_kernel(const SrmArgs A)
         V[2] -= mul_byte<2>(xa, xb);
         V[3] -= mul_byte<3>(xa, xb);
     };
-    // priming: rows ys - oy .. ys + ry - 1 (rows outside the image read as zeros)
-    for (int y = ys - oy; y < ys + ry; ++y) {
-        uint32_t pa, pb;
-        fetch(y, pa, pb);
-        add_row(pa, pb);
-    }
+    // The wave is alone with its memory round trips (two or three waves per SIMD at 4K, a step's arithmetic is ~60 instructions), so
+    // what it waits for is the NUMBER of round trips, not the bytes: the rows of DEPTH steps are in flight at once -- a group of
+    // DEPTH steps takes its rows from registers while the next group's 4 * DEPTH loads are on their way (round 4, second session:
+    // one step ahead and one load per priming row was 13.4 us per 4K plane at 9x9; strips of 16 rows then took 8 + 16 round trips).
+    constexpr int DEPTH = 8;
     // the store: outputs x0 + ox + 4 lane + j, j < nval
     const int xo = x0 + ox + 4 * lane;
     const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
     const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
     const bool ragged = __any(nval > 0 && nval < 4) != 0;
-    uint32_t ia, ib, oa, ob;
-    fetch(ys + ry, ia, ib);
-    fetch(ys - oy, oa, ob);
-    for (int y = ys; y < ye; ++y) {
-        uint32_t nia, nib, noa, nob; // the rows of the next step
-        fetch(y + 1 + ry, nia, nib);
-        fetch(y + 1 - oy, noa, nob);
-        add_row(ia, ib); // V = the vertical window of row y
+    uint32_t ia[DEPTH], ib[DEPTH], oa[DEPTH], ob[DEPTH];
+    // the first group's rows are issued BEFORE the priming rows are waited for: everything a strip needs up to its first DEPTH
+    // outputs is then one batch of loads when the window has no more than DEPTH + 1 rows
+#pragma unroll
+    for (int t = 0; t < DEPTH; ++t) fetch(ys + t + ry, ia[t], ib[t]), fetch(ys + t - oy, oa[t], ob[t]);
+    // priming: rows ys - oy .. ys + ry - 1 (rows outside the image read as zeros), DEPTH rows' loads in flight at a time
+    for (int y = ys - oy; y < ys + ry; y += DEPTH) {
+        uint32_t pa[DEPTH], pb[DEPTH];
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) fetch(y + t < ys + ry ? y + t : -1, pa[t], pb[t]); // (row -1 reads zeros: adds nothing)
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) add_row(pa[t], pb[t]);
+    }
+    for (int yg = ys; yg < ye; yg += DEPTH) {
+        uint32_t nia[DEPTH], nib[DEPTH], noa[DEPTH], nob[DEPTH]; // the rows of the next group
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) fetch(yg + DEPTH + t + ry, nia[t], nib[t]), fetch(yg + DEPTH + t - oy, noa[t], nob[t]);
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) {
+        const int y = yg + t;
+        if (y >= ye) break; // (wave-uniform)
+        add_row(ia[t], ib[t]); // V = the vertical window of row y
         *(int4 *)(row + 4 * lane) = int4{V[0], V[1], V[2], V[3]};
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -140,8 +153,95 @@ __global__ __launch_bounds__(256) void srm_u8_march_kernel(const SrmArgs A)
             for (int j = 0; j < 3; ++j)
                 __builtin_amdgcn_raw_buffer_store_b32((uint32_t)ov[j], rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
         }
-        sub_row(oa, ob); // row y - oy leaves
-        ia = nia, ib = nib, oa = noa, ob = nob;
+        sub_row(oa[t], ob[t]); // row y - oy leaves
+        }
+#pragma unroll
+        for (int t = 0; t < DEPTH; ++t) ia[t] = nia[t], ib[t] = nib[t], oa[t] = noa[t], ob[t] = nob[t];
+    }
+}
+
+// The same sums with a strip's rows fetched ALL AT ONCE (square windows of 3 ... 21, the only ones the reference calls with:
+// OptFlowCPU.cpp:344-345 9x9, OptFlowGpu.cu:1944-1945 19x19).  A strip is kSrmRows - (WH - 1) output rows, so the rows its windows
+// cover are exactly kSrmRows: 2 x 32 dword loads go out back to back, the wave pays ONE memory round trip instead of one per group
+// of eight rows, and the row that leaves a window is the register that entered it WH steps earlier -- no second fetch.  With the
+// window's height at compile time the whole strip is straight-line code.
+constexpr int kSrmRows = 32;
+
+template <int WW, int WH>
+__global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
+{
+    __shared__ __attribute__((aligned(16))) int lds[4 * kSrmWaveInts];
+    const int lane = (int)threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int item = (int)blockIdx.x * 4 + wv;
+    if (item >= A.tiles_x * A.strips) return;
+    const int tile = item % A.tiles_x, strip = item / A.tiles_x;
+    constexpr int ww = WW, wh = WH, SH = kSrmRows - (WH - 1);
+    const int w = A.w, h = A.h;
+    constexpr int ox = ww >> 1, oy = wh >> 1;
+    const int x0 = tile * A.out_w - ox;
+    const int cb = x0 + 4 * lane;
+    const int ys = strip * SH, ye = min(ys + SH, h);
+    int *row = lds + wv * kSrmWaveInts;
+    if (lane < kSrmPad / 4) *(int4 *)(row + 256 + 4 * lane) = int4{0, 0, 0, 0};
+
+    const __amdgpu_buffer_rsrc_t ra = srm_rsrc(A.a, (unsigned)w * (unsigned)h), rb = srm_rsrc(A.b, (unsigned)w * (unsigned)h);
+    const __amdgpu_buffer_rsrc_t rd = srm_rsrc(A.dst, (unsigned)w * (unsigned)h * 4u);
+    const int cbl = min(max(cb, 0), w - 4);
+    uint32_t sel = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = cb + j;
+        const uint32_t sj = (x >= 0 && x < w && x - cbl >= 0 && x - cbl < 4) ? (uint32_t)(x - cbl) : 0x0cu;
+        sel |= sj << (8 * j);
+    }
+    const uint32_t voff = (uint32_t)cbl;
+    uint32_t pa[kSrmRows], pb[kSrmRows];
+#pragma unroll
+    for (int t = 0; t < kSrmRows; ++t) {
+        const int y = ys - oy + t;
+        const int o = (uint32_t)y < (uint32_t)h ? y * w : kSrmOob; // (a row outside the image reads zeros)
+        pa[t] = __builtin_amdgcn_raw_buffer_load_b32(ra, voff, o, 0);
+        pb[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, voff, o, 0);
+    }
+    const int xo = x0 + ox + 4 * lane;
+    const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
+    const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
+    const bool ragged = __any(nval > 0 && nval < 4) != 0;
+    int V[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < kSrmRows; ++t) {
+        {
+            const uint32_t xa = __builtin_amdgcn_perm(0u, pa[t], sel), xb = __builtin_amdgcn_perm(0u, pb[t], sel);
+            V[0] += mul_byte<0>(xa, xb), V[1] += mul_byte<1>(xa, xb), V[2] += mul_byte<2>(xa, xb), V[3] += mul_byte<3>(xa, xb);
+        }
+        if (t < wh - 1) continue; // (compile time) the window is not complete yet
+        const int y = ys + t - (wh - 1);
+        if (y >= ye) break; // (wave-uniform)
+        *(int4 *)(row + 4 * lane) = int4{V[0], V[1], V[2], V[3]};
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int *src = row + 4 * lane;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < WW; ++k) acc += src[k];
+        const int o0 = acc;
+        const int o1 = o0 - src[0] + src[ww];
+        const int o2 = o1 - src[1] + src[ww + 1];
+        const int o3 = o2 - src[2] + src[ww + 2];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int so = __builtin_amdgcn_readfirstlane(y * w * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)o3}, rd, st_off, so, 2 /* nt */);
+        if (__builtin_expect(ragged, 0)) {
+            const int ov[4] = {o0, o1, o2, o3};
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)ov[j], rd, (nval < 4 && j < nval) ? (uint32_t)(xo + j) * 4u : (uint32_t)kSrmOob, so, 2);
+        }
+        {
+            const uint32_t xa = __builtin_amdgcn_perm(0u, pa[t - (wh - 1)], sel), xb = __builtin_amdgcn_perm(0u, pb[t - (wh - 1)], sel);
+            V[0] -= mul_byte<0>(xa, xb), V[1] -= mul_byte<1>(xa, xb), V[2] -= mul_byte<2>(xa, xb), V[3] -= mul_byte<3>(xa, xb);
+        }
     }
 }
 
@@ -334,6 +434,22 @@ int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int w
     A.a = d_a, A.b = d_b, A.dst = d_dst, A.w = w, A.h = h, A.ww = ww, A.wh = wh;
     A.out_w = (256 - (ww - 1)) & ~3;
     A.tiles_x = ofx_div_up(w, A.out_w);
+    // square windows up to 21: a strip's rows in one batch of loads (srm_u8_strip_kernel).  OFX_SRM_STRIP=0 keeps the grouped march.
+    static const bool strip_form = [] { const char *e = getenv("OFX_SRM_STRIP"); return !e || atoi(e) != 0; }();
+    if (strip_form && ww == wh && (ww & 1) && ww >= 3 && ww <= 21) {
+        A.strip_h = kSrmRows - (wh - 1);
+        A.strips = ofx_div_up(h, A.strip_h);
+        const int nblocks = ofx_div_up(A.tiles_x * A.strips, 4);
+        switch (ww) {
+#define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL((srm_u8_strip_kernel<N, N>), dim3((unsigned)nblocks), dim3(256), 0, st, A); break;
+            OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
+            OFX_SRM_CASE(19) OFX_SRM_CASE(21)
+#undef OFX_SRM_CASE
+        default: break;
+        }
+        OFX_HIP(hipGetLastError());
+        return OFX_OK;
+    }
     // strips: enough waves to fill the chip several times over (the kernel is latency-bound per wave), but long enough that the
     // wh - 1 priming rows stay a minor cost
     static const int target = env_pos("OFX_SRM_WAVES", 256 * 4 * 8);

@@ -80,7 +80,7 @@ class Session:
 
     def __init__(self, width: int, height: int, levels: int, window: int, mode: str = "lk_float", device: int = 0,
                  shard=None, iters: int = 1, local_corner: bool = False, patch_size: int = 0, stream_batch: int = 1, borrow_frames: bool = False,
-                 min_det: float = 0.0, two_stage: bool = False, strict: bool = True, frames_partial: bool = False):
+                 min_det: float = 0.0, two_stage: bool = False, strict: bool = True, frames_partial: bool = False, deep_fetch: int = 0):
         """strict: stream_drain() raises OfxError when the pipeline has drained and the session's status word is not 0 -- a pair
         whose result is NOT the reference's (a corner shift that left the patch of a session that cannot repair it, a shift or
         warp beyond a shard's halo; include/ofx.h, ofx_session_corner_status).  strict=False: poll corner_status() yourself."""
@@ -97,6 +97,9 @@ class Session:
         p.min_det = float(min_det)
         p.stream_two_stage = int(bool(two_stage))
         p.frames_partial = int(bool(frames_partial))   # (ofx_params.frames_partial: only the plan's rows + the patch were ever written)
+        # ofx_params.deep_fetch: +1 = the frames handed to the stream pipeline are cold (last touched more than an Infinity Cache of
+        # traffic ago), -1 = warm, 0 = decide by level size.  Speed only; the bits are the same.
+        p.deep_fetch = int(deep_fetch)
         self.shard = shard
         if shard is not None:
             p.sharded = 1

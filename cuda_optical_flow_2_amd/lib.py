@@ -38,7 +38,7 @@ class Params(C.Structure):
                 ("buf_y0", C.c_int * OFX_MAX_LEVELS), ("buf_y1", C.c_int * OFX_MAX_LEVELS),
                 ("comp_y0", C.c_int * OFX_MAX_LEVELS), ("comp_y1", C.c_int * OFX_MAX_LEVELS),
                 ("iters", C.c_int), ("local_corner", C.c_int), ("patch_size", C.c_int), ("stream_batch", C.c_int), ("borrow_frames", C.c_int), ("min_det", C.c_float),
-                ("stream_two_stage", C.c_int), ("frames_partial", C.c_int)]
+                ("stream_two_stage", C.c_int), ("frames_partial", C.c_int), ("deep_fetch", C.c_int)]
 
 
 _vp = C.c_void_p

@@ -204,6 +204,7 @@ typedef struct ofx_stream_stages {
     int n_corner;
     ofx_lk_desc lk[OFX_MAX_LK_ITEMS]; /* the LK items of every pair of the tick (levels x pairs <= OFX_MAX_LK_ITEMS) */
     int n_lk;
+    int deep_fetch; /* 0 = by size, +1 / -1 = deep / one-step row fetch of the LK stage (see ofx_params.deep_fetch; OFX_LK_DMA overrides) */
 } ofx_stream_stages;
 int ofx_stream_launch(const ofx_stream_stages *stages, int window, int mode, void *stream);
 /* Measurement hook: with a device buffer of 8 * capacity_blocks uint64 set, every wave of every later ofx_stream_launch
@@ -418,6 +419,13 @@ typedef struct ofx_params {
      * patch's extent only and the repair of a shift that leaves the patch is OFF (it would rebuild from rows that are not
      * there): such a pair raises bit k of the status word, as with copied frames, and is an error.  Not with stream_two_stage. */
     int frames_partial;
+    /* Where the stream tick's LK stage expects its image rows to come from (ABI v10).  0 = decide by the size of the largest level
+     * (levels of 16 Mpx and more: deep fetch); +1 = the frames handed over are COLD -- they were last touched more than an
+     * Infinity Cache (256 MiB) of traffic ago, e.g. a long pool of decoded surfaces that is consumed much later than it is
+     * written: fetch rows two steps ahead straight into LDS (ofx_stream_stages.deep_fetch; measured on MI355X with a ring of 44
+     * 4K frames: 272.8 vs 287.2 us per tick of eight pairs, 1080p 137.8 vs 142.8); -1 = they are warm (just written by a producer, or a
+     * short ring): fetch one step ahead (2 % faster then).  A hint about speed only: every choice gives the same bits. */
+    int deep_fetch;
 } ofx_params;
 
 int ofx_session_create(const ofx_params *p, ofx_session **out);

@@ -21,7 +21,7 @@ def test_library_loads_and_reports_abi():
     from cuda_optical_flow_2_amd import lib
 
     L = lib.load()
-    assert L.ofx_abi_version() == 9
+    assert L.ofx_abi_version() == 10
     assert isinstance(L.ofx_last_error(), bytes)
 
 

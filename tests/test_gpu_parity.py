@@ -819,6 +819,30 @@ def _stream_all_pairs(s, frames, L, B):
     return got
 
 
+@pytest.mark.parametrize("cfg", [(1280, 720, 4, 9, "lk_float", 4, True), (1000, 564, 3, 7, "lk_float", 2, False), (640, 480, 3, 5, "compat_cpu", 4, True),
+                                 (1920, 1080, 4, 15, "lk_float_fast", 2, True)])
+@pytest.mark.parametrize("hint", [1, -1])
+def test_deep_fetch_hint_changes_no_bit(eng, cfg, hint):
+    """ofx_params.deep_fetch (ABI v10) says where the caller's frames come from -- +1: cold, the tick's LK stage fetches its rows two
+    steps ahead straight into LDS; -1: warm, one step ahead -- and is a hint about speed only: every pair of a stream carries the
+    bits of the plain pair-at-a-time sequence (the one the oracle tests pin) under either value, in two stages and in three."""
+    import torch
+
+    w, h, L, win, mode, B, two_stage = cfg
+    frames = [torch.from_numpy(synth.smooth_pair(w, h, 1.5 * i, -0.75 * i, seed=77)[1]).cuda() for i in range(3 * B + 2)]
+    want = _plain_sequence(eng, frames, w, h, L, win, mode)
+    s = eng.Session(w, h, L, win, mode, stream_batch=B, borrow_frames=True, two_stage=two_stage, deep_fetch=hint)
+    got = _stream_all_pairs(s, frames, L, B)
+    assert s.corner_status() == 0
+    s.close()
+    assert sorted(got) == list(range(1, len(frames)))
+    for p in got:
+        for k in range(L):
+            assert_same(got[p][k], want[p][k], f"deep_fetch {hint:+d}: {mode} pair {p} level {k}")
+    with pytest.raises(Exception):
+        eng.Session(w, h, L, win, mode, deep_fetch=2)
+
+
 @pytest.mark.parametrize("kind", ["two_stage", "local_corner"])
 @pytest.mark.parametrize("batch", [1, 2, 4])
 def test_corner_shift_that_leaves_the_patch_is_repaired(eng, oracle, kind, batch, monkeypatch):
