@@ -340,7 +340,7 @@ int ofx_shift_table(const ofx_shift_desc *levels, int n, ShiftTable *out, int *b
         t.lv[m] = ShiftArgs{levels[i].d_src, levels[i].d_dst, levels[i].d_uv, g->w, g->h, g->pitch, g->row0, g->row0 + g->rows,
                             g->out_y0, g->out_y1, bx};
         t.first_block[m] = blocks;
-        blocks += bx * (g->out_y1 - g->out_y0);
+        blocks += bx * ofx_div_up(g->out_y1 - g->out_y0, ofx_dev::kShiftRows);
         ++m;
     }
     t.n = m;

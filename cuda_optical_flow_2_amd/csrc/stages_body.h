@@ -299,9 +299,20 @@ struct ShiftTable { // (level, pair) items: up to the levels of every pair of a 
     int n;
 };
 
-// one 256-thread block of the multi-level shift: a thread moves 16 adjacent pixels of a row (four groups of four).  With
-// one group per thread the launch was bound by the rate at which waves can be started -- 43 k waves for a 4K pyramid's 11
-// Mpx, 15 us for 22 MB of traffic -- and not by anything the waves did.
+// one 256-thread block of the multi-level shift: a thread moves 16 adjacent pixels (four groups of four) of kShiftRows rows.
+// Nothing branches between the loads (round 4, second session):
+//   * the column map does not depend on the row and is formed once per thread: per group of four pixels a base column (the
+//     -- generally unaligned -- dword that holds the targets of its in-image pixels), a byte selector and a mask;
+//   * all rows' dwords are issued together; a wave that holds a border of the image (some pixel's target lies outside: that
+//     pixel keeps its own value where cpu::shift_back_pyramid's memcpy of w * h bytes put one, OptFlowCPU.cpp:247,270-273 -- the
+//     first third of the 3-channel positions -- and is zero after it) also fetches the pixels' own dwords and merges by v_perm;
+//   * a column map that does not fit that form (never seen: it needs |u| beyond 2^23) is served byte by byte.
+// Measured, and recorded because it was not what the rewrite was for: in front of a tick of eight 4K pairs with iterations this
+// launch takes 65 us for its 177 MB (0.34 of the roofline) in EVERY form tried -- one row per thread with a branch per group (the
+// form of rounds 1-3: 65-69 us, 138 k waves), four rows per thread (68), this one (65, 17 k waves, 32 dwords in flight per lane)
+// -- so neither its wave count nor what a lane keeps in flight bounds it; it runs right behind an accumulating launch's 0.7 GB of
+// streaming stores, whose lines the memory side is still writing back when its cold reads arrive.
+constexpr int kShiftRows = 8;
 __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int tid)
 {
     if (blk >= T.first_block[T.n]) return;
@@ -313,62 +324,135 @@ __device__ __forceinline__ void shift_block(const ShiftTable &T, int blk, int ti
     }
     const ShiftArgs &A = T.lv[level];
     const int block = blk - T.first_block[level];
-    const int bx = block % A.blocks_x, by = block / A.blocks_x;
+    // (the division runs on the vector unit: readfirstlane puts its -- uniform -- results back into scalar registers, so that the
+    // row pointers below are scalar and every load is `uniform base + 32-bit lane offset`, one address register instead of two)
+    const int by = __builtin_amdgcn_readfirstlane(block / A.blocks_x), bx = __builtin_amdgcn_readfirstlane(block - by * A.blocks_x);
     const int xt = 16 * (bx * 256 + tid);
-    const int y = A.out_y0 + by;
-    if (xt >= A.pitch || y >= A.out_y1) return;
-    const float u = A.uv[0], v = A.uv[1];
-    const float ty = (float)y + v;
-    const bool yin = ty > -1.0f && ty < (float)A.h;
-    const int ny = yin ? (int)ty : 0;
-    const bool yhave = ny >= A.row0 && ny < A.row_end;
-    const uint8_t *srow = A.src + (size_t)((yhave ? ny : A.row0) - A.row0) * (size_t)A.pitch;
-    const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
-    const long long third = (long long)A.w * (long long)A.h;
-    uint32_t res[4] = {0u, 0u, 0u, 0u};
+    const int y0 = A.out_y0 + by * kShiftRows;
+    if (xt >= A.pitch || y0 >= A.out_y1) return;
+    // (the shift vector comes through a vector load: uniform, but in vector registers until readfirstlane)
+    const float u = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.uv[0])));
+    const float v = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, A.uv[1])));
+    const long long third = ((long long)A.w * (long long)A.h + 2) / 3; // 3 * pos < w * h  <=>  pos < ceil(w * h / 3)
+    // the column map of the thread's 16 pixels
+    uint32_t base[4], own0[4], sel[4], vmask[4];
+    bool weird = false, partial = false;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int x0 = xt + 4 * g;
-        if (x0 >= A.pitch) continue;
-        // target columns of this group's 4 pixels (the column map does not depend on the row)
         int nx[4];
         bool xin[4];
+        int ref = x0;
+        bool have = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float tx = (float)(x0 + k) + u;
             xin[k] = (x0 + k) < A.w && tx > -1.0f && tx < (float)A.w;
             nx[k] = xin[k] ? (int)tx : 0;
+            if (xin[k] && !have) ref = nx[k] - k, have = true;
         }
-        uint32_t out;
-        if (yin && yhave && xin[0] && xin[1] && xin[2] && xin[3] && nx[1] == nx[0] + 1 && nx[2] == nx[0] + 2 && nx[3] == nx[0] + 3) {
-            // common case: four consecutive in-image targets -> one (generally unaligned) dword instead of four byte
-            // gathers; byte gathers cost a full address cycle per lane
-            __builtin_memcpy(&out, srow + nx[0], 4);
-        } else {
-            out = 0;
+        const int b0 = min(max(ref, 0), A.pitch - 4);
+        uint32_t sg = 0u, vm = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int x = x0 + k;
-                int val = 0;
-                if (x < A.w) {
-                    if (yin && yhave && xin[k]) {
-                        val = srow[nx[k]];
-                    } else {
-                        val = (3ll * ((long long)y * A.w + x) < third) ? own[x] : 0;
-                    }
-                }
-                out |= (uint32_t)val << (8 * k);
+        for (int k = 0; k < 4; ++k) {
+            const int b = nx[k] - b0;
+            if (xin[k]) {
+                weird = weird || b < 0 || b > 3;
+                sg |= (uint32_t)(b & 3) << (8 * k);
+                vm |= 0xffu << (8 * k);
+            } else {
+                sg |= (uint32_t)(4 + k) << (8 * k); // the pixel's own byte (second operand of the permute)
             }
         }
-        res[g] = out;
+        base[g] = (uint32_t)b0, own0[g] = (uint32_t)min(x0, A.pitch - 4), sel[g] = sg, vmask[g] = vm;
+        if (x0 < A.pitch) partial = partial || vm != 0xffffffffu;
     }
-    uint8_t *drow = A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + xt;
-    if (xt + 16 <= A.pitch && (A.pitch & 15) == 0 && ((uintptr_t)A.dst & 15) == 0) {
-        *reinterpret_cast<uint4 *>(drow) = make_uint4(res[0], res[1], res[2], res[3]);
-    } else {
+    const bool wide = xt + 16 <= A.pitch && (A.pitch & 15) == 0 && ((uintptr_t)A.dst & 15) == 0;
+    // the row map: where row y's pixels come from (block-uniform)
+    auto row_src = [&](int y, bool &ok) -> const uint8_t * {
+        const float ty = (float)y + v;
+        const bool yin = ty > -1.0f && ty < (float)A.h;
+        const int ny = yin ? (int)ty : 0;
+        ok = yin && ny >= A.row0 && ny < A.row_end;
+        return A.src + (size_t)((ok ? ny : y) - A.row0) * (size_t)A.pitch;
+    };
+    // bytes of the dword at (y, x0) that keep the pixel's own value when nothing is shifted onto it: x < w and inside the first third
+    auto own_mask = [&](int y, int x0) -> uint32_t {
+        long long lead = third - ((long long)y * A.w + x0);
+        const long long inw = (long long)A.w - x0;
+        lead = lead < inw ? lead : inw;
+        return lead >= 4 ? 0xffffffffu : (lead <= 0 ? 0u : (1u << (8 * (int)lead)) - 1u);
+    };
+    auto store_row = [&](int y, const uint32_t (&res)[4]) {
+        uint8_t *drow = A.dst + (size_t)(y - A.row0) * (size_t)A.pitch + xt;
+        if (wide) {
+            *reinterpret_cast<uint4 *>(drow) = make_uint4(res[0], res[1], res[2], res[3]);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (xt + 4 * g < A.pitch) *reinterpret_cast<uint32_t *>(drow + 4 * g) = res[g];
+            for (int g = 0; g < 4; ++g)
+                if (xt + 4 * g < A.pitch) *reinterpret_cast<uint32_t *>(drow + 4 * g) = res[g];
+        }
+    };
+    if (!__any(weird)) {
+        const bool border = __any(partial) != 0; // (wave-uniform)
+        uint32_t S[kShiftRows][4], O[kShiftRows][4];
+#pragma unroll
+        for (int r = 0; r < kShiftRows; ++r) {
+            const int y = min(y0 + r, A.out_y1 - 1); // (rows past the end repeat the last one and are not stored)
+            bool ok;
+            const uint8_t *srow = row_src(y, ok);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) __builtin_memcpy(&S[r][g], srow + (ok ? base[g] : own0[g]), 4); // (uniform row base + 32-bit lane offset)
+        }
+        if (border) {
+#pragma unroll
+            for (int r = 0; r < kShiftRows; ++r) {
+                const int y = min(y0 + r, A.out_y1 - 1);
+                const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) __builtin_memcpy(&O[r][g], own + own0[g], 4);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kShiftRows; ++r) {
+            const int y = y0 + r;
+            if (y >= A.out_y1) break; // (block-uniform)
+            bool ok;
+            (void)row_src(y, ok);
+            uint32_t res[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (!ok) res[g] = S[r][g] & own_mask(y, xt + 4 * g); // (S is the pixels' own dword then)
+                else if (border) res[g] = __builtin_amdgcn_perm(O[r][g], S[r][g], sel[g]) & (vmask[g] | own_mask(y, xt + 4 * g));
+                else res[g] = __builtin_amdgcn_perm(0u, S[r][g], sel[g]);
+            }
+            store_row(y, res);
+        }
+        return;
+    }
+    // any other column map: byte by byte, a row at a time
+    for (int r = 0; r < kShiftRows; ++r) {
+        const int y = y0 + r;
+        if (y >= A.out_y1) break;
+        bool ok;
+        const uint8_t *srow = row_src(y, ok);
+        const uint8_t *own = A.src + (size_t)(y - A.row0) * (size_t)A.pitch;
+        uint32_t res[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t out = 0u;
+#pragma nounroll
+            for (int k = 0; k < 4; ++k) {
+                const int x = xt + 4 * g + k;
+                const float tx = (float)x + u;
+                const bool shifted = ok && x < A.w && tx > -1.0f && tx < (float)A.w;
+                const bool keep = x < A.w && (shifted || (long long)y * A.w + x < third);
+                const uint32_t b = shifted ? srow[(int)tx] : own[min(x, A.pitch - 1)];
+                out |= (keep ? b : 0u) << (8 * k);
+            }
+            res[g] = out;
+        }
+        store_row(y, res);
     }
 }
 

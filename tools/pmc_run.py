@@ -19,7 +19,9 @@ if TWO and (B < 5 or B * w * h < 30e6):   # (bench.py's plan_stream: a short lau
     B = engine.suggest_stream_batch(w, h, L, None, True, False)
 if iters > 1 and path == "stream":
     B = bench.iters_batch(w, h, L)   # (bench.py: pairs per launch of a stream with refinement iterations)
-s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters, two_stage=TWO)
+RING = (bench.cold_ring_size(B, TWO, w * h) if "--warm" not in sys.argv else bench.ring_size(B, TWO)) if path == "stream" else 0   # bench.py's ring: longer than the Infinity Cache
+s = engine.Session(w, h, L, win, mode, stream_batch=B if path == "stream" else 1, borrow_frames=path == "stream", iters=iters, two_stage=TWO,
+                   deep_fetch=bench.frames_hint(RING, w * h) if path == "stream" else 0)   # (as bench.py tells its sessions)
 st = torch.cuda.Stream()
 with torch.cuda.stream(st):
     if path == "plain":
@@ -28,7 +30,7 @@ with torch.cuda.stream(st):
         for i in range(6):
             s.run_flow()
     else:
-        ring = bench.cold_ring_size(B, TWO, w * h) if "--warm" not in sys.argv else bench.ring_size(B, TWO)   # bench.py's ring: longer than the Infinity Cache
+        ring = RING
         frames = [torch.from_numpy(synth.smooth_pair(w, h, 2.0 * (i % 4), 1.0 * (i % 4))[1]).cuda() for i in range(ring)]
         s.stream_begin()
         for i in range((10 if iters <= 1 else 6) * B):
