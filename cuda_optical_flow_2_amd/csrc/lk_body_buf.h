@@ -174,7 +174,7 @@ __device__ __forceinline__ void lk_wave_buf(const LkTable &T, int wave, int lane
     [[maybe_unused]] WarpRowState WM;
     if constexpr (WOUT) {
         pin_scalar(A.warp_scale);
-        rs_wsrc = make_rsrc(A.warp_src, plane_bytes);
+        rs_wsrc = make_rsrc(A.warp_src, plane_bytes + (OFX_WARP_LEAN ? 3 : 0)); // (lk_body_warp.h: a tap dword may start in the plane's last three bytes)
         rs_wout = make_rsrc(A.warp_out, plane_bytes);
         const bool out_lane = lane >= G::LO_LANE && lane <= G::HI_LANE && cb < A.w;
         wvo = out_lane ? (uint32_t)cb : (uint32_t)kOob; // (a level whose width is no multiple of 4 ends inside the dword: the rest is row padding)

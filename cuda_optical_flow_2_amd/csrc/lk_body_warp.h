@@ -26,7 +26,8 @@ namespace ofx_dev {
 #endif
 struct WarpRowState {      // a row of a lane between the two stages
     float fx[4], fy[4];    // the fractions of the source coordinates
-#if OFX_WARP_PACK_SEL
+#if OFX_WARP_LEAN
+#elif OFX_WARP_PACK_SEL
     uint32_t selp;         // bits 4k .. 4k+1: xi - xb of pixel k, bits 4k+2 .. 4k+3: x1 - xb
 #else
     uint32_t sel[4];       // per pixel the byte selector (xi - xb, x1 - xb, zero, zero) into its two dwords (general rows only)
@@ -46,12 +47,25 @@ struct WarpRowState {      // a row of a lane between the two stages
 #ifndef OFX_WARP_FAST_ROWS
 #define OFX_WARP_FAST_ROWS 0
 #endif
+// Round 4, second session: NO row is general.  The dword fetched AT byte xi of a tap row holds p(xi) in byte 0 and p(xi + 1) in byte 1
+// whenever p(xi + 1) is looked at: (a) the right tap is only replaced by the pixel itself (replicate border) for xi = w - 1, and there
+// the source column was clamped to w - 1, its fraction is 0 and p + 0 * (q - p) is p for every byte q -- whatever byte 1 holds;
+// (b) a dword that starts in the last three bytes of the row pitch runs into the next row, but its bytes 0 and 1 are still this
+// row's (xi <= w - 1 < pitch, and xi + 1 <= w - 1 when it counts).  What is left is the dword that starts in the last three bytes of the
+// LAST row of the plane: the resource is declared three bytes longer than the rows (lk_body_buf.h), which is why d_warp_src must be
+// followed by three readable bytes (include/ofx.h; every plane of a session is followed by 64).  No selector, no pull-back, no
+// permute: ~40 vector instructions per row step less than the general form (of ~500) and four registers (sel[]) -- and, unlike
+// OFX_WARP_FAST_ROWS, no branch.  Same bytes (the iteration tests compare against the warp launch and the oracle).  0 = the general form.
+#ifndef OFX_WARP_LEAN
+#define OFX_WARP_LEAN 1
+#endif
 
 __device__ __forceinline__ void warp_row_clear(WarpRowState &M)
 {
 #pragma unroll
     for (int k = 0; k < 4; ++k) M.fx[k] = M.fy[k] = 0.0f, M.ra[k] = M.rb[k] = 0u;
-#if OFX_WARP_PACK_SEL
+#if OFX_WARP_LEAN
+#elif OFX_WARP_PACK_SEL
     M.selp = 0u; // (both taps byte 0 of a zero dword: the pending row of the first emitting step is stored nowhere)
 #else
     for (int k = 0; k < 4; ++k) M.sel[k] = 0x0c0c0c0cu;
@@ -88,6 +102,20 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
             yb[k] = min(max(yb[k], row0), row_end - 1) - row0;
         }
     }
+#if OFX_WARP_LEAN
+    M.general = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#ifdef OFX_X_NO_TAPS // (diagnostic build: no tap loads)
+        M.ra[k] = (uint32_t)(ya[k] * pitch + xi[k]), M.rb[k] = (uint32_t)(yb[k] * pitch + xi[k]);
+#else
+        M.ra[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(ya[k] * pitch + xi[k]), 0, 0);
+        M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(yb[k] * pitch + xi[k]), 0, 0);
+#endif
+    }
+    (void)wmax;
+    return;
+#else
     // the common row: every tap dword can be fetched at byte xi itself and holds p(xi), p(xi + 1) in its bytes 0 and 1
     const int xlim = min(pitch - 4, w - 2);
     M.general = !OFX_WARP_FAST_ROWS || __any(max(max(xi[0], xi[1]), max(xi[2], xi[3])) > xlim) != 0;
@@ -117,6 +145,7 @@ __device__ __forceinline__ void warp_row_prepare(const __amdgpu_buffer_rsrc_t &r
             M.rb[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, (uint32_t)(yb[k] * pitch + xi[k]), 0, 0);
         }
     }
+#endif
 }
 
 // Stage 2: the taps have arrived; the row's four bytes.
@@ -131,6 +160,11 @@ __device__ __forceinline__ uint32_t warp_row_finish(const WarpRowState &M)
         const float v = a + M.fy[k] * (b - a);
         out |= ((uint32_t)(int)(v + 0.5f) & 0xffu) << (8 * k);
     };
+#if OFX_WARP_LEAN
+#pragma unroll
+    for (int k = 0; k < 4; ++k) blend(k, M.ra[k], M.rb[k]);
+    return out;
+#else
     if (__builtin_expect(M.general, 0)) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -146,6 +180,7 @@ __device__ __forceinline__ uint32_t warp_row_finish(const WarpRowState &M)
         for (int k = 0; k < 4; ++k) blend(k, M.ra[k], M.rb[k]);
     }
     return out;
+#endif
 }
 
 } // namespace ofx_dev

@@ -141,9 +141,15 @@ static ofx_geom level_geom(const ofx_session *s, int k, int out0, int out1)
     return g;
 }
 
-extern "C" int ofx_session_create(const ofx_params *p, ofx_session **out)
+extern "C" int ofx_session_create(const ofx_params *p_in, ofx_session **out)
 {
-    OFX_REQUIRE(p && out, "ofx_session_create: null argument");
+    OFX_REQUIRE(p_in && out, "ofx_session_create: null argument");
+    // The fused warp of a refinement iteration fetches a tap's dword AT the tap's byte (lk_body_warp.h): its source must be followed by
+    // three readable bytes.  Every plane of a session is (by 64); the one warp source that would be a caller's buffer is level 0 of
+    // a single-level session on borrowed frames -- such a session copies its frames instead (and runs its stream in three stages).
+    ofx_params eff = *p_in;
+    if (eff.levels == 1 && eff.iters > 1 && eff.borrow_frames) eff.borrow_frames = 0, eff.stream_two_stage = 0;
+    const ofx_params *p = &eff;
     OFX_REQUIRE(p->width > 0 && p->height > 0, "ofx_session_create: bad size %dx%d", p->width, p->height);
     OFX_REQUIRE(p->levels >= 1 && p->levels <= OFX_MAX_LEVELS, "ofx_session_create: levels %d out of range", p->levels);
     OFX_REQUIRE(p->window >= 3 && (p->window & 1), "ofx_session_create: window must be odd and >= 3");

@@ -112,6 +112,9 @@ typedef struct ofx_lk_desc {
      * the NEXT refinement iteration reads as its d_next -- d_warp_out = ofx_warp_levels(d_warp_src, the flow this launch leaves in
      * d_flow, warp_scale), same bytes -- so that only a pair's first refinement iteration needs ofx_warp_levels.  d_warp_src is the
      * warp source (the globally shifted next image), d_warp_out a plane of the level's geometry other than d_next and d_warp_src.
+     * d_warp_src MUST BE FOLLOWED BY THREE READABLE BYTES (ABI v10: the launch fetches a tap's dword at the tap's own byte, also in
+     * the last three columns of the plane's last row; the bytes beyond the plane are never looked at.  Every plane of an ofx_session
+     * is followed by 64.)
      * For all descriptors of a launch or for none.  On a row window (a shard: geom.row0 / rows / out rows are not the whole level)
      * d_warp_out receives the out rows, a tap row outside [row0, row0 + rows) is replaced by the nearest row held, and bit
      * warp_status_bit of *d_warp_status (optional) is set when a pixel with a finite flow needed such a row. */
@@ -400,7 +403,9 @@ typedef struct ofx_params {
      * launches read it in place).  There the buffer of a frame is read until the run_flow of the pair in which it is the
      * PREVIOUS frame has run, and its pitch must be the session's level-0 pitch (the width rounded up to 64 bytes,
      * ofx_session_plane reports it) at a 4-byte aligned address; host frames (ofx_session_set_frame_host*) and the staged
-     * path still copy. */
+     * path still copy.  A single-level session with refinement iterations (levels == 1, iters > 1) copies its frames whatever
+     * this flag says (and ignores stream_two_stage): its level 0 would be the fused warp's source, which must be followed by three
+     * readable bytes (ofx_lk_desc.d_warp_src). */
     int borrow_frames;
     /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */
     float min_det;

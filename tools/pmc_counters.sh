@@ -11,9 +11,14 @@ cd $R
 PROG=${PMC_PROG:-tools/pmc_run.py}
 EXTRA=()
 if [ -n "$PMC_LDS" ]; then EXTRA=("SQ_INSTS_LDS SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT"); fi
-for C in "${EXTRA[@]}" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE"; do
+SETS=("${EXTRA[@]}" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE")
+# PMC_MEM=1: the memory side instead -- what the L2s ask of the fabric, how long the requests stay out, who stalls whom
+if [ -n "$PMC_MEM" ]; then SETS=("GRBM_GUI_ACTIVE" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum" "TCC_EA0_WRREQ_LEVEL_sum TCC_BUSY_sum" "TCC_TAG_STALL_sum TCC_HIT_sum TCC_MISS_sum" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum"); fi
+# (a pass with TA_BUSY_avr / TA_*_STALLED_BY_TC_CYCLES_sum never returned on this pool: left out; every pass has its own time limit)
+for C in "${SETS[@]}"; do
   T=$(echo $C | tr ' ' '_')
-  rocprofv3 --pmc $C --output-format csv -d $O/$T -- python $PROG "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
+  timeout -k 10 ${PMC_PASS_LIMIT:-150} rocprofv3 --pmc $C --output-format csv -d $O/$T -- python $PROG "$@" > /dev/null 2> $O/$T.err || echo "pass $T failed"
+  echo "pass $T done" >> $O/progress.txt
 done
 python - "$O" "$K" <<'PY'
 import csv, glob, os, sys
