@@ -611,6 +611,39 @@ class Run:
         sess.timing(0)
         self.dt = self.max_over_ranks(dt)
 
+    # ---- board power and clock while the timed steps run (outside the timed region) -----------------------------------------
+    def sample_power(self):
+        """Best effort, single GPU only: ~2.5 s of the very steps that were timed are enqueued again and `rocm-smi` reads the board
+        power and the shader clock about a second into them.  Round 4 found the pipeline at the board's power limit (1 400 W on
+        MI355X: profiles/r04_power_clock.txt) -- a faster launch is answered by a lower clock -- so the line says what it drew.
+        OFX_BENCH_POWER=0 skips it.  Returns a dict or None; never raises."""
+        import re, shutil, subprocess
+
+        if self.distributed or os.environ.get("OFX_BENCH_POWER", "1") == "0" or shutil.which("rocm-smi") is None:
+            return None
+        try:
+            per_step = self.dt / max(1, self.args.steps)
+            n = int(min(40000, max(8, 2.5 / max(per_step, 1e-6))))
+            p = subprocess.Popen("sleep 1.0; rocm-smi --showpower --showclocks --showmaxpower", shell=True, stdout=subprocess.PIPE,
+                                 stderr=subprocess.STDOUT, text=True)
+            t0 = time.perf_counter()
+            for i in range(n):
+                self.step(i)
+            self.torch.cuda.synchronize()
+            busy_s = time.perf_counter() - t0
+            text = p.communicate(timeout=20)[0]
+            watts = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", text) or re.search(r"Average Graphics Package Power \(W\):\s*([0-9.]+)", text)
+            cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
+            sclk = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", text)
+            if not watts:
+                return None
+            return {"board_w": float(watts.group(1)), "limit_w": float(cap.group(1)) if cap else None,
+                    "sclk_mhz": int(sclk.group(1)) if sclk else None, "gpu_busy_s": round(busy_s, 2),
+                    "how": "rocm-smi, one reading ~1 s into a re-run of the timed steps (outside the timed region); a board at its limit "
+                           "answers a faster launch with a lower clock (DESIGN.md 4.2c)"}
+        except Exception:
+            return None
+
     # ---- self-check: the session that was just timed against an independent plain session ----------------------------
     def self_check(self):
         """After the timed region: a short stream through the SAME session (same plan: frames per launch, borrowed ring,
@@ -1258,6 +1291,8 @@ class Run:
             "roofline": dict(dom, timed_in="second pass over the same steps with hipEventRecord around each launch on its stream", traffic=traffic, **traffic_src),
         }
         out["roofline"]["whole_pair"] = whole
+        if getattr(self, "power", None):
+            out["power"] = self.power
         if self.rccl_world is not None:
             out["rccl_world"] = self.rccl_world   # sum of ones over the communicator: the ranks RCCL actually connected
         if extra:
@@ -1277,6 +1312,7 @@ def main():
     run = Run(args)
     run.build_headline()
     run.time_headline()
+    run.power = run.sample_power()
     # (timing experiments with ablated kernels, OFX_BUILD_DEFS=-DOFX_X_*: their results are wrong by construction)
     check_msg = "SKIPPED (OFX_BENCH_SKIP_CHECK)" if os.environ.get("OFX_BENCH_SKIP_CHECK") == "1" else run.self_check()
     if run.distributed:
