@@ -13,7 +13,7 @@ cd $R
 pmc() { # name, kernel substring, skip, pmc_run args...
   n=$1; k=$2; skip=$3; shift 3
   for C in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n/$C -- python tools/pmc_run.py "$@" > $O/pmc_${n}_$C.out 2> $O/pmc_${n}_$C.err
+    timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n/$C -- python tools/pmc_run.py "$@" > $O/pmc_${n}_$C.out 2> $O/pmc_${n}_$C.err
   done
   python tools/pmc_parse.py $O/pmc_$n "$k" $skip | tee -a $O/summary/${TAG}_traffic_pmc.jsonl
 }
@@ -49,7 +49,7 @@ cat $O/summary/traffic_latest.json
 cp $O/summary/traffic_latest.json $R/profiles/traffic_latest.json
 stats() { # name, bench args...
   n=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
   f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench4k_${n}_kernel_stats.csv
   echo "== $n"; head -4 "$f"
 }
@@ -62,7 +62,7 @@ stats compat_cpu --iters 1 --mode compat_cpu
 stats random --iters 1 --frames random
 # the other BASELINE configurations as written: file names say which
 stats8() { n=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
   f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench_${n}_kernel_stats.csv
   echo "== $n"; head -4 "$f"
 }
