@@ -69,3 +69,18 @@ def test_default_arguments_name_the_config_as_written():
     assert r["frac"] < r["frac_r02_accounting"]   # the old accounting counted bytes of launches that no longer run
     d = bench.dominant_block(kinds, 8, 3840, 2160, 5, 5)
     assert d["kind"] == "lk_acc_warp" and d["algorithmic_bytes_per_launch"] == 8 * 20 * sum(px)
+
+
+def test_frames_hint_follows_the_ring_against_the_infinity_cache(monkeypatch):
+    """bench.py tells its stream sessions where their frames come from (ofx_params.deep_fetch): +1 for a ring of never-rewritten
+    buffers longer than the 256 MiB Infinity Cache (each buffer comes back from HBM), -1 for one that fits; an override for A/Bs."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.delenv("OFX_BENCH_DEEP_FETCH", raising=False)
+    px4k = 3840 * 2160
+    assert bench.frames_hint(bench.cold_ring_size(8, True, px4k), px4k) == 1
+    assert bench.frames_hint(bench.ring_size(8, True), px4k) == -1          # 20 x 8.3 MB = 166 MB
+    assert bench.frames_hint(16, 7680 * 4320) == 1
+    monkeypatch.setenv("OFX_BENCH_DEEP_FETCH", "0")
+    assert bench.frames_hint(1000, px4k) == 0

@@ -4,6 +4,8 @@ d = json.load(open(sys.argv[1]))
 r = d["roofline"]
 print(f"value {d['value']} {d['unit']}  ms/step {d['ms_per_step']}  frames/step {d['frames_per_step']}  check {d['self_check']}")
 print(f"roofline[{r.get('kind')}] frac {r['frac']} launch {r['avg_launch_us']} us  whole pair: frac {r['whole_pair']['frac']} {r['whole_pair']['kernel_us_per_pair']} us/pair  traffic {r.get('traffic')}")
+if "power" in d:
+    print("power", d["power"].get("board_w"), "W of", d["power"].get("limit_w"), " sclk", d["power"].get("sclk_mhz"), "MHz")
 for k, v in r["whole_pair"]["launches"].items():
     print(f"   {k:12s} {v['avg_us']:9.2f} us x {v['launches_per_pair']}")
 for k, v in d.get("extra", {}).items():
