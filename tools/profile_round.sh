@@ -8,10 +8,15 @@ TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
-rm -rf $O; mkdir -p $O/summary
+# PROFILE_ONLY="name name ...": only those steps (pmc: stream iter2 iter1 plain compat; stats: headline iters1 ... 1080p_iters1), into the
+# directory as it stands -- to finish a round that a failing step cut short
+want() { [ -z "$PROFILE_ONLY" ] || [[ " $PROFILE_ONLY " == *" $1 "* ]]; }
+[ -n "$PROFILE_ONLY" ] || rm -rf $O
+mkdir -p $O/summary
 cd $R
 pmc() { # name, kernel substring, skip, pmc_run args...
   n=$1; k=$2; skip=$3; shift 3
+  want $n || return 0
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$n/$C -- python tools/pmc_run.py "$@" > $O/pmc_${n}_$C.out 2> $O/pmc_${n}_$C.err
   done
@@ -23,6 +28,7 @@ pmc iter1 "lk_iter_kernel<4, 1, false, 1," 1 4k stream lk_float 5
 pmc plain lk_level_kernel 1 4k plain lk_float
 pmc compat stream_kernel 3 4k stream compat_cpu
 # traffic per launch for bench.py's roofline.traffic (keys: bench.py line(): tkey)
+if want stream; then
 python - $O/summary/${TAG}_traffic_pmc.jsonl $O > $O/summary/traffic_latest.json <<'PY'
 import json, re, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.strip()]
@@ -47,8 +53,10 @@ PY
 cat $O/summary/traffic_latest.json
 # the bench lines below carry this figure: bench.py reads profiles/traffic_latest.json and checks its kernel_source_sha16 against the sources
 cp $O/summary/traffic_latest.json $R/profiles/traffic_latest.json
+fi
 stats() { # name, bench args...
   n=$1; shift
+  want $n || return 0
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench4k_$n.json 2> $O/$n.err
   f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench4k_${n}_kernel_stats.csv
   echo "== $n"; head -4 "$f"
@@ -62,6 +70,7 @@ stats compat_cpu --iters 1 --mode compat_cpu
 stats random --iters 1 --frames random
 # the other BASELINE configurations as written: file names say which
 stats8() { n=$1; shift
+  want $n || return 0
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$n -- python bench.py --no-cpu-baseline --no-extras "$@" > $O/summary/${TAG}_bench_$n.json 2> $O/$n.err
   f=$(find $O/$n -name "*kernel_stats.csv" | head -1); cp "$f" $O/summary/${TAG}_bench_${n}_kernel_stats.csv
   echo "== $n"; head -4 "$f"
