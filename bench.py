@@ -621,6 +621,7 @@ class Run:
 
         if self.distributed or os.environ.get("OFX_BENCH_POWER", "1") == "0" or shutil.which("rocm-smi") is None:
             return None
+        p = None
         try:
             per_step = self.dt / max(1, self.args.steps)
             n = int(min(40000, max(8, 2.5 / max(per_step, 1e-6)))) // 4 * 4   # (a multiple of the four resident frames: the
@@ -643,6 +644,11 @@ class Run:
                     "how": "rocm-smi, one reading ~1 s into a re-run of the timed steps (outside the timed region); a board at its limit "
                            "answers a faster launch with a lower clock (DESIGN.md 4.2c)"}
         except Exception:
+            try:
+                if p is not None:
+                    p.kill()
+            except Exception:
+                pass
             return None
 
     # ---- self-check: the session that was just timed against an independent plain session ----------------------------
