@@ -148,16 +148,26 @@ __global__ __launch_bounds__(256) void conv_3ch_1ch_kernel(const uint8_t *src3, 
 // skipped by the reference; here it enters as pixel value 0, which leaves the float accumulator unchanged (+-0 added to a sum that
 // cannot be -0) and the truncating int accumulator too as long as it stays below 2^24 (the host checks the mask: sum |m| * 255).
 // Threads whose window touches the image's left or right edge take the loop of the kernel above.
-template <bool F32_OUT, int MW>
+// MH > 0: the mask's height at compile time (square masks: the reference's 3x3 and 5x5).  The loads of a thread's kConvRows + MH - 1
+// source rows are then ALL issued before the first is used (one memory round trip per thread instead of one per mask row); a row
+// outside the image is fetched through the resource's range check and enters as zeros, which is the reference's skip by the argument
+// above; every output pixel still receives its taps in the reference's row-major order.  Measured at 4K, 3x3 (second session of round
+// 4): 24.0-25.7 us against 27.7-27.9 row by row (u8), 25.0 against 26.2 (float).  kConvRows = 4 (four output rows per thread from six
+// source rows: half the loads per pixel, a quarter of the waves) was built too and is SLOWER, 40-41 us: the launch is bound neither
+// by its load count nor by the rate at which waves start.  0: M.mh at run time, row by row.
+constexpr int kConvRows = 1;
+template <bool F32_OUT, int MW, int MH = 0>
 __global__ __launch_bounds__(256) void conv_3ch_1ch_x4_kernel(const uint8_t *src3, int w, int h, void *dst, const MaskArg M)
 {
     constexpr int NP = 4 + MW - 1;              // source pixels per row
     constexpr int ND = (3 * (NP - 1) + 1 + 3) / 4; // dwords that hold their channel-0 bytes
-    const int x0 = 4 * ((int)blockIdx.x * 64 + ((int)threadIdx.x & 63)), y = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6);
-    if (x0 >= w || y >= h) return;
+    constexpr int RPT = MH > 0 ? kConvRows : 1; // output rows per thread
+    const int x0 = 4 * ((int)blockIdx.x * 64 + ((int)threadIdx.x & 63)), y0 = ((int)blockIdx.y * 4 + ((int)threadIdx.x >> 6)) * RPT;
+    if (x0 >= w || y0 >= h) return;
     const int ox = MW >> 1, oy = M.mh >> 1;
     const bool inner = x0 - ox >= 0 && x0 + NP - ox <= w && x0 + 4 <= w && (3ll * ((long long)w * h) >= 3ll * ((long long)(h - 1) * w + x0 - ox) + 4 * ND);
     if (!inner) { // the image's edges: pixel by pixel, as conv_3ch_1ch_kernel
+        for (int y = y0; y < min(y0 + RPT, h); ++y)
         for (int x = x0; x < min(x0 + 4, w); ++x) {
             int ia = 0;
             float fa = 0.f;
@@ -186,6 +196,53 @@ __global__ __launch_bounds__(256) void conv_3ch_1ch_x4_kernel(const uint8_t *src
     const uint32_t b0 = 3u * (uint32_t)(x0 - ox);
     int ia[4] = {0, 0, 0, 0};
     float fa[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] const int y = y0;
+    auto put = [&](int yy) {
+        if constexpr (F32_OUT) {
+            float *d = static_cast<float *>(dst) + (size_t)yy * w + x0;
+            if (((uintptr_t)d & 15) == 0) *reinterpret_cast<float4 *>(d) = float4{fa[0], fa[1], fa[2], fa[3]}; // (one 16-byte store per lane)
+            else d[0] = fa[0], d[1] = fa[1], d[2] = fa[2], d[3] = fa[3];
+        } else {
+            uint8_t *d = static_cast<uint8_t *>(dst) + (size_t)yy * w + x0;
+            const uint32_t pk = ((uint32_t)ia[0] & 0xffu) | (((uint32_t)ia[1] & 0xffu) << 8) | (((uint32_t)ia[2] & 0xffu) << 16) | ((uint32_t)ia[3] << 24);
+            if (((uintptr_t)d & 3) == 0) *reinterpret_cast<uint32_t *>(d) = pk;
+            else d[0] = (uint8_t)ia[0], d[1] = (uint8_t)ia[1], d[2] = (uint8_t)ia[2], d[3] = (uint8_t)ia[3];
+        }
+    };
+    if constexpr (MH > 0) {
+        constexpr int NR = RPT + MH - 1;
+        uint32_t dw[NR][ND];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int ty = y0 - oy + i;
+            const int ro = (uint32_t)ty < (uint32_t)h ? ty * w * 3 : (int)0x80000000; // (outside the image: beyond the resource, reads 0)
+#pragma unroll
+            for (int k = 0; k < ND; ++k) dw[i][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, b0 + 4u * (uint32_t)k, ro, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            if (y0 + r >= h) break; // (uniform over the wave)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ia[j] = 0, fa[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < MH; ++i) {
+                float px[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) px[j] = (float)((dw[r + i][(3 * j) >> 2] >> (8 * ((3 * j) & 3))) & 0xffu); // (v_cvt_f32_ubyteN)
+#pragma unroll
+                for (int q = 0; q < MW; ++q) {
+                    const float m = M.m[i * MW + q];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (F32_OUT) fa[j] += px[j + q] * m;
+                        else ia[j] = (int)((float)ia[j] + px[j + q] * m);
+                    }
+                }
+            }
+            put(y0 + r);
+        }
+        return;
+    }
     for (int i = 0; i < M.mh; ++i) {
         const int ty = y - oy + i;
         if (ty < 0 || ty >= h) continue; // (uniform over the wave: one row per wave)
@@ -206,16 +263,7 @@ __global__ __launch_bounds__(256) void conv_3ch_1ch_x4_kernel(const uint8_t *src
             }
         }
     }
-    if constexpr (F32_OUT) {
-        float *d = static_cast<float *>(dst) + (size_t)y * w + x0;
-        if (((uintptr_t)d & 15) == 0) *reinterpret_cast<float4 *>(d) = float4{fa[0], fa[1], fa[2], fa[3]}; // (one 16-byte store per lane)
-        else d[0] = fa[0], d[1] = fa[1], d[2] = fa[2], d[3] = fa[3];
-    } else {
-        uint8_t *d = static_cast<uint8_t *>(dst) + (size_t)y * w + x0;
-        const uint32_t pk = ((uint32_t)ia[0] & 0xffu) | (((uint32_t)ia[1] & 0xffu) << 8) | (((uint32_t)ia[2] & 0xffu) << 16) | ((uint32_t)ia[3] << 24);
-        if (((uintptr_t)d & 3) == 0) *reinterpret_cast<uint32_t *>(d) = pk;
-        else d[0] = (uint8_t)ia[0], d[1] = (uint8_t)ia[1], d[2] = (uint8_t)ia[2], d[3] = (uint8_t)ia[3];
-    }
+    put(y);
 }
 
 // OptFlowGpu.cu:1463-1502 / :1549-1588: window clipped at the border, taps in row-major order
@@ -1063,6 +1111,13 @@ template <bool F32_OUT>
 int launch_conv_x4(const uint8_t *d_src3, int w, int h, void *d_dst, const MaskArg &M, hipStream_t st)
 {
     const dim3 grid(ofx_div_up(w, 256), ofx_div_up(h, 4));
+    static const bool rows_at_once = [] { const char *e = getenv("OFX_CONV_ROWS"); return !e || atoi(e) != 0; }(); // (0: row by row)
+    const dim3 grid_r(ofx_div_up(w, 256), ofx_div_up(h, 4 * kConvRows));
+    if (rows_at_once && M.mw == 3 && M.mh == 3) {
+        hipLaunchKernelGGL((conv_3ch_1ch_x4_kernel<F32_OUT, 3, 3>), grid_r, dim3(256), 0, st, d_src3, w, h, d_dst, M);
+    } else if (rows_at_once && M.mw == 5 && M.mh == 5) {
+        hipLaunchKernelGGL((conv_3ch_1ch_x4_kernel<F32_OUT, 5, 5>), grid_r, dim3(256), 0, st, d_src3, w, h, d_dst, M);
+    } else
     switch (M.mw) {
     case 2: hipLaunchKernelGGL((conv_3ch_1ch_x4_kernel<F32_OUT, 2>), grid, dim3(256), 0, st, d_src3, w, h, d_dst, M); break;
     case 3: hipLaunchKernelGGL((conv_3ch_1ch_x4_kernel<F32_OUT, 3>), grid, dim3(256), 0, st, d_src3, w, h, d_dst, M); break;
