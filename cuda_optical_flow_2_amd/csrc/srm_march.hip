@@ -265,22 +265,29 @@ struct SrmFArgs {
 constexpr int kSrmFRps = 4;          // output rows per step of the float march
 constexpr int kSrmFRow = 256 + 64; // floats per ring row (the reads of the lanes past the tile's last output land in the pad)
 
-// (one wave per block: the ring of a 19x19 window is 24 KB, and a block's LDS is what limits how many waves a CU holds)
-template <int WW>
-__global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
+// NW = 1: one wave per block.  NW = 2 (round 4, second session; windows of 13 rows and more): TWO waves share one ring -- a block's LDS
+// is what limits how many waves a CU holds (the ring of a 19x19 window is 28 KB: one wave per SIMD, which issues v_add_f32 at half the
+// rate two do), and two waves on one ring of wh + 2 * RPS - 1 rows need 33 KB together.  A step then produces 2 * RPS output rows: wave v
+// puts the product rows y + ry + v * RPS + o and accumulates the output rows y + v * RPS + o; a block barrier separates the puts from
+// the accumulation and the accumulation from the next step's puts.
+template <int WW, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void srm_f32_march_kernel(const SrmFArgs A)
 {
-    extern __shared__ __attribute__((aligned(16))) float ring_all[]; // wh rows x kSrmFRow
-    const int lane = (int)threadIdx.x, wv = 0;
+    extern __shared__ __attribute__((aligned(16))) float ring_all[]; // (wh + NW * RPS - 1) rows x kSrmFRow
+    const int lane = (int)threadIdx.x & 63, wv = NW > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0;
     const int item = (int)blockIdx.x;
-    if (item >= A.tiles_x * A.strips) return;
+    if (item >= A.tiles_x * A.strips) return; // (block-uniform)
+    auto block_sync = [&] {
+        if constexpr (NW > 1) __syncthreads();
+    };
     const int tile = item % A.tiles_x, strip = item / A.tiles_x;
     const int ww = WW > 0 ? WW : A.ww, wh = A.wh, w = A.w, h = A.h;
     const int ox = ww >> 1, oy = wh >> 1, ry = wh - 1 - oy;
     const int x0 = tile * A.out_w - ox;
     const int cb = x0 + 4 * lane;
     const int ys = strip * A.strip_h, ye = min(ys + A.strip_h, h);
-    float *ring = ring_all + (size_t)wv * (size_t)(wh + kSrmFRps - 1) * kSrmFRow;
-    for (int r = 0; r < wh + kSrmFRps - 1; ++r)
+    float *ring = ring_all; // (one ring per block)
+    for (int r = wv; r < wh + NW * kSrmFRps - 1; r += NW)
         if (lane < 16) *(float4 *)(ring + r * kSrmFRow + 256 + 4 * lane) = float4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const __amdgpu_buffer_rsrc_t ra = srm_rsrc(A.a, (unsigned)w * (unsigned)h * 4u), rb = srm_rsrc(A.b, (unsigned)w * (unsigned)h * 4u);
@@ -304,7 +311,8 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
     // RPS output rows per step share their product rows: a row of products is read from LDS once and feeds the accumulators of every
     // output row whose window holds it -- each output still receives its own taps in row-major order
     constexpr int RPS = kSrmFRps;
-    const int nslots = wh + RPS - 1;
+    const int nslots = wh + NW * RPS - 1; // rows of the ring
+    const int nrows_w = wh + RPS - 1;     // product rows one wave's RPS output rows cover
     auto slot_of = [&](int r) {
         int sl = r % nslots;
         return sl < 0 ? sl + nslots : sl;
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
     };
     // priming, eight rows' loads in flight at a time (one wave per SIMD is all the ring's LDS allows: a load per iteration would
     // expose a memory round trip per primed row -- 18 of them for a 19-row window)
-    for (int y = ys - oy; y < ys + ry; y += 8) {
+    for (int y = ys - oy + 8 * wv; y < ys + ry; y += 8 * NW) {
         float4 pa[8], pb[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) pa[t] = fetch(ra, y + t), pb[t] = fetch(rb, y + t);
@@ -334,19 +342,21 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
     const bool ragged = __any(nval > 0 && nval < 4) != 0;
     float4 na[RPS], nb[RPS];
 #pragma unroll
-    for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, ys + ry + o), nb[o] = fetch(rb, ys + ry + o);
-    for (int y = ys; y < ye; y += RPS) {
+    for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, ys + wv * RPS + ry + o), nb[o] = fetch(rb, ys + wv * RPS + ry + o);
+    for (int yb = ys; yb < ye; yb += NW * RPS) {
+        const int y = yb + wv * RPS; // this wave's first output row of the step
 #pragma unroll
         for (int o = 0; o < RPS; ++o) put_row_s(y + ry + o, na[o], nb[o]);
 #pragma unroll
-        for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, y + RPS + ry + o), nb[o] = fetch(rb, y + RPS + ry + o); // the next step's rows, a step ahead
+        for (int o = 0; o < RPS; ++o) na[o] = fetch(ra, y + NW * RPS + ry + o), nb[o] = fetch(rb, y + NW * RPS + ry + o); // the next step's rows, a step ahead
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        block_sync(); // (the other wave's product rows)
         float acc[RPS][4];
 #pragma unroll
         for (int o = 0; o < RPS; ++o) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0.0f;
         int slot = slot_of(y - oy);
-        for (int p = 0; p < nslots; ++p) { // product rows y - oy + p, top to bottom
+        for (int p = 0; p < nrows_w; ++p) { // product rows y - oy + p, top to bottom
             const float *src = ring + slot * kSrmFRow + 4 * lane;
             if constexpr (WW > 0) {
                 float t[WW + 3];
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(64) void srm_f32_march_kernel(const SrmFArgs A)
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        block_sync(); // (the next step's puts overwrite rows the other wave may still be reading)
 #pragma unroll
         for (int o = 0; o < RPS; ++o) {
             if (y + o >= ye) break;
@@ -489,11 +500,48 @@ int ofx_srm_f32_march(const float *d_a, const float *d_b, int w, int h, int ww, 
     static const int min_strip = env_pos("OFX_SRMF_MIN_STRIP", 0);
     const int min_h = min_strip ? min_strip : 8;
     if (strip_h < min_h) strip_h = min_h;
-    strip_h = (strip_h + kSrmFRps - 1) / kSrmFRps * kSrmFRps; // whole steps
+    // two waves on one ring where one wave's ring would leave fewer than two waves per SIMD (OFX_SRMF_NW = 1 / 2 overrides)
+    static const int nw_forced = env_pos("OFX_SRMF_NW", 0);
+    int nw = nw_forced == 1 || nw_forced == 2 ? nw_forced : (wh >= 5 ? 2 : 1);
+    if ((size_t)(wh + 2 * kSrmFRps - 1) * kSrmFRow * sizeof(float) > 64u * 1024u) nw = 1; // (a block's dynamic LDS)
+    const int step_rows = nw * kSrmFRps;
+    if (nw == 2 && strip_h < 2 * step_rows) strip_h = 2 * step_rows;
+    // ONE residency round: the blocks a CU holds are set by the ring's LDS (four at 19x19), a block lives for its whole strip, and a
+    // second round that fills a fraction of the chip costs a whole strip's time (measured at 4K 19x19, strips of 16 / 32 / 48 rows =
+    // 2.2 / 1.1 / 0.75 rounds: 128 / 143 / 105 us) -- so the strips are made just tall enough for every block to be resident at once
+    // (OFX_SRMF_MIN_STRIP set: that height instead)
+    if (!min_strip) {
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+            return n;
+        }();
+        const size_t lds_block = (size_t)(wh + step_rows - 1) * kSrmFRow * sizeof(float);
+        int per_cu = (int)((size_t)160 * 1024 / lds_block);
+        per_cu = per_cu < 1 ? 1 : (per_cu * nw > 32 ? 32 / nw : per_cu); // (at most eight waves per SIMD)
+        const int strips_max = cus * per_cu / A.tiles_x;
+        if (strips_max >= 1) {
+            const int need = ofx_div_up(h, strips_max);
+            if (need > strip_h) strip_h = need;
+        }
+    }
+    strip_h = (strip_h + step_rows - 1) / step_rows * step_rows; // whole steps
     A.strip_h = strip_h;
     A.strips = ofx_div_up(h, strip_h);
     const int blocks = A.tiles_x * A.strips;
-    const size_t lds = (size_t)(wh + kSrmFRps - 1) * kSrmFRow * sizeof(float);
+    const size_t lds = (size_t)(wh + step_rows - 1) * kSrmFRow * sizeof(float);
+    if (nw == 2) {
+        switch (ww) {
+#define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL((srm_f32_march_kernel<N, 2>), dim3((unsigned)blocks), dim3(128), lds, st, A); break;
+            OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
+            OFX_SRM_CASE(19) OFX_SRM_CASE(21) OFX_SRM_CASE(23)
+#undef OFX_SRM_CASE
+        default: hipLaunchKernelGGL((srm_f32_march_kernel<0, 2>), dim3((unsigned)blocks), dim3(128), lds, st, A); break;
+        }
+        OFX_HIP(hipGetLastError());
+        return OFX_OK;
+    }
     switch (ww) {
 #define OFX_SRM_CASE(N) case N: hipLaunchKernelGGL(srm_f32_march_kernel<N>, dim3((unsigned)blocks), dim3(64), lds, st, A); break;
         OFX_SRM_CASE(3) OFX_SRM_CASE(5) OFX_SRM_CASE(7) OFX_SRM_CASE(9) OFX_SRM_CASE(11) OFX_SRM_CASE(13) OFX_SRM_CASE(15) OFX_SRM_CASE(17)
