@@ -146,7 +146,7 @@ extern "C" int ofx_session_create(const ofx_params *p_in, ofx_session **out)
     OFX_REQUIRE(p_in && out, "ofx_session_create: null argument");
     // The fused warp of a refinement iteration fetches a tap's dword AT the tap's byte (lk_body_warp.h): its source must be followed by
     // three readable bytes.  Every plane of a session is (by 64); the one warp source that would be a caller's buffer is level 0 of
-    // a single-level session on borrowed frames -- such a session copies its frames instead (and runs its stream in three stages).
+    // a single-level session on borrowed frames (pair at a time: the stream pipeline needs two levels) -- such a session copies its frames.
     ofx_params eff = *p_in;
     if (eff.levels == 1 && eff.iters > 1 && eff.borrow_frames) eff.borrow_frames = 0, eff.stream_two_stage = 0;
     const ofx_params *p = &eff;

@@ -404,7 +404,7 @@ typedef struct ofx_params {
      * PREVIOUS frame has run, and its pitch must be the session's level-0 pitch (the width rounded up to 64 bytes,
      * ofx_session_plane reports it) at a 4-byte aligned address; host frames (ofx_session_set_frame_host*) and the staged
      * path still copy.  A single-level session with refinement iterations (levels == 1, iters > 1) copies its frames whatever
-     * this flag says (and ignores stream_two_stage): its level 0 would be the fused warp's source, which must be followed by three
+     * this flag says (pair at a time: the stream pipeline needs two levels): its level 0 would be the fused warp's source, which must be followed by three
      * readable bytes (ofx_lk_desc.d_warp_src). */
     int borrow_frames;
     /* determinant guard of the solve, see ofx_lk_desc.min_det (0 = the reference: flat regions are NaN) */

@@ -843,6 +843,31 @@ def test_deep_fetch_hint_changes_no_bit(eng, cfg, hint):
         eng.Session(w, h, L, win, mode, deep_fetch=2)
 
 
+def test_single_level_session_with_iterations_on_borrowed_frames(eng):
+    """The fused warp of a refinement iteration fetches a tap's dword at the tap's own byte (lk_body_warp.h), so its source must be
+    followed by three readable bytes.  Every plane of a session is; the one warp source that would be a caller's buffer is level 0
+    of a single-level session on borrowed frames (pair at a time: the stream pipeline needs two levels), which therefore COPIES its
+    frames whatever borrow_frames says (include/ofx.h).  The frames here are exactly-sized tensors, and the flow of noise frames sends
+    taps to the last rows' last columns; every pair must carry the bits of the session that copies."""
+    import torch
+
+    w, h, L, win, iters = 640, 360, 1, 9, 4
+    frames = [torch.from_numpy(synth.random_pair(w, h, seed=300 + i)[0]).cuda() for i in range(4)]
+    got = {}
+    for borrow in (False, True):
+        s = eng.Session(w, h, L, win, "lk_float", iters=iters, borrow_frames=borrow)
+        s.set_frame_device(frames[0]); s.build_pyramid(); s.swap()
+        got[borrow] = []
+        for i in range(1, len(frames)):
+            s.set_frame_device(frames[i]); s.build_pyramid(); s.run_flow()
+            torch.cuda.synchronize()
+            got[borrow].append(s.flow_host(0))
+            s.swap()
+        s.close()
+    for i, (a, b) in enumerate(zip(got[False], got[True])):
+        assert_same(b, a, f"single level, {iters} iterations, borrowed frames, pair {i + 1}")
+
+
 @pytest.mark.parametrize("kind", ["two_stage", "local_corner"])
 @pytest.mark.parametrize("batch", [1, 2, 4])
 def test_corner_shift_that_leaves_the_patch_is_repaired(eng, oracle, kind, batch, monkeypatch):
