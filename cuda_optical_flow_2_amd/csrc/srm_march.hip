@@ -36,6 +36,20 @@ __device__ __forceinline__ int mul_byte(uint32_t x, uint32_t y)
     return (int)(((x >> (8 * J)) & 0xffu) * ((y >> (8 * J)) & 0xffu)); // (selects as v_mul_u32_u24_sdwa BYTE_J x BYTE_J)
 }
 
+// lane l receives lane l - 1's / lane l + 1's value (zero at the wave's ends): DPP wave shifts, as the LK march's derivative stage
+__device__ __forceinline__ int srm_from_left(int x)
+{
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ int srm_from_right(int x)
+{
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 struct SrmArgs {
     const uint8_t *a, *b;
     int32_t *dst;
@@ -166,6 +180,9 @@ __global__ __launch_bounds__(256) void srm_u8_march_kernel(const SrmArgs A)
 // of eight rows, and the row that leaves a window is the register that entered it WH steps earlier -- no second fetch.  With the
 // window's height at compile time the whole strip is straight-line code.
 constexpr int kSrmRows = 32;
+#ifndef OFX_SRM_NEIGH
+#define OFX_SRM_NEIGH 1 // (0: every window through LDS)
+#endif
 
 template <int WW, int WH>
 __global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
@@ -178,7 +195,11 @@ __global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
     constexpr int ww = WW, wh = WH, SH = kSrmRows - (WH - 1);
     const int w = A.w, h = A.h;
     constexpr int ox = ww >> 1, oy = wh >> 1;
-    const int x0 = tile * A.out_w - ox;
+    // NEIGH (windows up to 9 columns): a lane's four outputs are the columns of its own four sums, and their windows reach no further
+    // than the neighbouring lanes' -- eight DPP moves instead of the round trip through LDS (a write, a wait, three 16-byte reads: the
+    // longest dependent stretch of a step, with one or two waves per SIMD to hide it).  Lanes 1 .. 62 produce outputs: 248 columns.
+    constexpr bool NEIGH = OFX_SRM_NEIGH && WW <= 9;
+    const int x0 = tile * A.out_w - (NEIGH ? 4 : ox);
     const int cb = x0 + 4 * lane;
     const int ys = strip * SH, ye = min(ys + SH, h);
     int *row = lds + wv * kSrmWaveInts;
@@ -203,8 +224,9 @@ __global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
         pa[t] = __builtin_amdgcn_raw_buffer_load_b32(ra, voff, o, 0);
         pb[t] = __builtin_amdgcn_raw_buffer_load_b32(rb, voff, o, 0);
     }
-    const int xo = x0 + ox + 4 * lane;
-    const int nval = max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
+    const int xo = NEIGH ? x0 + 4 * lane : x0 + ox + 4 * lane; // the lane's first output column
+    const int nval = NEIGH ? ((lane >= 1 && lane <= 62) ? max(0, min(4, min(A.out_w - 4 * (lane - 1), w - xo))) : 0)
+                           : max(0, min(4, min(A.out_w - 4 * lane, w - xo)));
     const uint32_t st_off = nval == 4 ? (uint32_t)xo * 4u : (uint32_t)kSrmOob;
     const bool ragged = __any(nval > 0 && nval < 4) != 0;
     int V[4] = {0, 0, 0, 0};
@@ -217,6 +239,20 @@ __global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
         if (t < wh - 1) continue; // (compile time) the window is not complete yet
         const int y = ys + t - (wh - 1);
         if (y >= ye) break; // (wave-uniform)
+        int o0, o1, o2, o3;
+        if constexpr (NEIGH) {
+            // E[e] = the vertical sum of column (4 lane - 4 + e): the left neighbour's four, this lane's, the right neighbour's
+            int E[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) E[j] = srm_from_left(V[j]), E[4 + j] = V[j], E[8 + j] = srm_from_right(V[j]);
+            int acc = 0;
+#pragma unroll
+            for (int e = 4 - ox; e <= 4 + ox; ++e) acc += E[e];
+            o0 = acc;
+            o1 = o0 - E[4 - ox] + E[5 + ox];
+            o2 = o1 - E[5 - ox] + E[6 + ox];
+            o3 = o2 - E[6 - ox] + E[7 + ox];
+        } else {
         *(int4 *)(row + 4 * lane) = int4{V[0], V[1], V[2], V[3]};
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -224,12 +260,13 @@ __global__ __launch_bounds__(256) void srm_u8_strip_kernel(const SrmArgs A)
         int acc = 0;
 #pragma unroll
         for (int k = 0; k < WW; ++k) acc += src[k];
-        const int o0 = acc;
-        const int o1 = o0 - src[0] + src[ww];
-        const int o2 = o1 - src[1] + src[ww + 1];
-        const int o3 = o2 - src[2] + src[ww + 2];
+        o0 = acc;
+        o1 = o0 - src[0] + src[ww];
+        o2 = o1 - src[1] + src[ww + 1];
+        o3 = o2 - src[2] + src[ww + 2];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        }
         const int so = __builtin_amdgcn_readfirstlane(y * w * 4);
         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{(uint32_t)o0, (uint32_t)o1, (uint32_t)o2, (uint32_t)o3}, rd, st_off, so, 2 /* nt */);
         if (__builtin_expect(ragged, 0)) {
@@ -448,6 +485,7 @@ int ofx_srm_u8_march(const uint8_t *d_a, const uint8_t *d_b, int w, int h, int w
     // square windows up to 21: a strip's rows in one batch of loads (srm_u8_strip_kernel).  OFX_SRM_STRIP=0 keeps the grouped march.
     static const bool strip_form = [] { const char *e = getenv("OFX_SRM_STRIP"); return !e || atoi(e) != 0; }();
     if (strip_form && ww == wh && (ww & 1) && ww >= 3 && ww <= 21) {
+        if (OFX_SRM_NEIGH && ww <= 9) A.out_w = 248, A.tiles_x = ofx_div_up(w, A.out_w); // (lanes 1 .. 62 of a wave produce outputs)
         A.strip_h = kSrmRows - (wh - 1);
         A.strips = ofx_div_up(h, A.strip_h);
         const int nblocks = ofx_div_up(A.tiles_x * A.strips, 4);
