@@ -483,7 +483,9 @@ class Run:
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            import datetime
+            # (a collective that never completes ends the run after four minutes instead of RCCL's default ten: nothing here takes long)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank), timeout=datetime.timedelta(seconds=240))
             dist.barrier()
             # proof that RCCL saw every rank: a one-element all-reduce of ones over the communicator the run uses
             ones = torch.ones(1, dtype=torch.int32, device="cuda")
