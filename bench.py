@@ -384,6 +384,16 @@ def frames_hint(n_buffers, frame_bytes):
     return 1 if n_buffers * frame_bytes > INFINITY_CACHE_BYTES else -1
 
 
+def parse_rocm_smi(text):
+    """board watts, their limit and the shader clock out of `rocm-smi --showpower --showclocks --showmaxpower` (None where a line is missing)"""
+    import re
+
+    watts = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", text) or re.search(r"Average Graphics Package Power \(W\):\s*([0-9.]+)", text)
+    cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
+    sclk = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", text)
+    return (float(watts.group(1)) if watts else None, float(cap.group(1)) if cap else None, int(sclk.group(1)) if sclk else None)
+
+
 def make_ring(src, n):
     """n DISTINCT device buffers whose contents repeat every len(src) buffers"""
     return [src[i % len(src)] if i < len(src) else src[i % len(src)].clone() for i in range(n)]
@@ -636,13 +646,10 @@ class Run:
             self.torch.cuda.synchronize()
             busy_s = time.perf_counter() - t0
             text = p.communicate(timeout=20)[0]
-            watts = re.search(r"Current Socket Graphics Package Power \(W\):\s*([0-9.]+)", text) or re.search(r"Average Graphics Package Power \(W\):\s*([0-9.]+)", text)
-            cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", text)
-            sclk = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", text)
-            if not watts:
+            watts, cap, sclk = parse_rocm_smi(text)
+            if watts is None:
                 return None
-            return {"board_w": float(watts.group(1)), "limit_w": float(cap.group(1)) if cap else None,
-                    "sclk_mhz": int(sclk.group(1)) if sclk else None, "gpu_busy_s": round(busy_s, 2),
+            return {"board_w": watts, "limit_w": cap, "sclk_mhz": sclk, "gpu_busy_s": round(busy_s, 2),
                     "how": "rocm-smi, one reading ~1 s into a re-run of the timed steps (outside the timed region); a board at its limit "
                            "answers a faster launch with a lower clock (DESIGN.md 4.2c)"}
         except Exception:

@@ -84,3 +84,20 @@ def test_frames_hint_follows_the_ring_against_the_infinity_cache(monkeypatch):
     assert bench.frames_hint(16, 7680 * 4320) == 1
     monkeypatch.setenv("OFX_BENCH_DEEP_FETCH", "0")
     assert bench.frames_hint(1000, px4k) == 0
+
+
+def test_power_reading_is_parsed_from_rocm_smi_text():
+    """bench.py's `power` field (the stream launches run at the board's power limit) comes from rocm-smi's text"""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    text = (
+        "WARNING: AMD GPU device(s) is/are in a low-power state. Check power control/runtime_status\\n"
+        "GPU[0]\\t\\t: fclk clock level: 0: (1250Mhz)\\n"
+        "GPU[0]\\t\\t: mclk clock level: 0: (2000Mhz)\\n"
+        "GPU[0]\\t\\t: sclk clock level: 1: (2184Mhz)\\n"
+        "GPU[0]\\t\\t: socclk clock level: S: (72Mhz)\\n"
+        "GPU[0]\\t\\t: Current Socket Graphics Package Power (W): 1374.0\\n"
+        "GPU[0]\\t\\t: Max Graphics Package Power (W): 1400.0\\n")
+    assert bench.parse_rocm_smi(text) == (1374.0, 1400.0, 2184)
+    assert bench.parse_rocm_smi("no such tool") == (None, None, None)
